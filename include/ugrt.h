@@ -1,0 +1,245 @@
+/*
+ * ugrt.h -- C-ABI of the MI355X-native grid ray tracer (libugrt.so).
+ *
+ * Drop-in boundary for the render hot path of sushruta/uniformgrid-raytracing.
+ * The reference has no FFI; its operator API is the set of C++ methods that
+ * display() calls (main.cu:59-302).  Every entry point below names the
+ * reference method it replaces (file:line under /root/reference) and keeps the
+ * reference's argument ORDER, so a shim class with the reference's method names
+ * is a one-liner.
+ *
+ * Conventions
+ *  - plain C, pointers + sizes only; "d_" = device pointer (HIP), everything
+ *    else is host memory.  The caller owns what it passes in; the context owns
+ *    what it hands out (grid arrays stay valid until the next build of the
+ *    same grid or ugrt_ctx_destroy).
+ *  - every function returns 0 on success, a UGRT_E* code otherwise, and
+ *    ugrt_last_error() describes the failure.  (The reference aborts the
+ *    process instead: cutilSafeCall / exit(-1), frustum_grid.h:127-131.)
+ *  - all device work is enqueued on the context's stream (ugrt_ctx_set_stream);
+ *    functions that must return a host value (ugrt_grid_get_info,
+ *    ugrt_sort_rays' chunk count) synchronise that stream.
+ *  - there is NO CPU fallback: a device entry point fails with UGRT_ENODEV
+ *    when no HIP device is usable.
+ *  - matrices are OpenGL column-major, indices int32/uint32, geometry fp32,
+ *    image uint8 RGB, pixel id = row*width + col with row 0 at the BOTTOM of
+ *    the view (trace_kernel.cu:91).
+ */
+#ifndef UGRT_H
+#define UGRT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UGRT_VERSION 100
+
+enum {
+	UGRT_OK = 0,
+	UGRT_EINVAL = 1, /* bad argument / unsupported configuration */
+	UGRT_ENODEV = 2, /* no usable HIP device */
+	UGRT_EHIP = 3,   /* a HIP runtime call failed */
+	UGRT_EIO = 4,    /* file could not be opened / parsed */
+	UGRT_ENOMEM = 5
+};
+
+/* flags in ugrt_config.flags */
+enum {
+	/* trace every shadow chunk instead of reproducing the reference's launch
+	 * (block b handles chunk b-1, at most nbx*nby blocks: light_kernel.cu:76-85,
+	 * per_frame_funcs.h:144) */
+	UGRT_FLAG_SHADOW_ALL_CHUNKS = 1u
+};
+
+/* which grid of the context */
+enum { UGRT_GRID_PERSPECTIVE = 0, UGRT_GRID_SPHERICAL = 1, UGRT_GRID_UNIFORM = 2 };
+
+/* stages timed by the built-in hipEvent profiler (ugrt_prof_*) */
+enum {
+	UGRT_ST_BUILD_COUNT = 0, /* DSKernel / DS_spherical_Kernel / uniform count */
+	UGRT_ST_BUILD_SCAN,      /* cudppScan inclusive, frustum_grid.h:249 */
+	UGRT_ST_BUILD_FILL,      /* DSFillkernel */
+	UGRT_ST_BUILD_SORT,      /* cudppSort, frustum_grid.h:298 */
+	UGRT_ST_BUILD_BOUNDS,    /* do_scan_dump .. cudppScan exclusive */
+	UGRT_ST_TRACE_PRIMARY,   /* rckernel_alpha */
+	UGRT_ST_MAP_RAYS,        /* mapSort_Effective_kernel */
+	UGRT_ST_SORT_RAYS,       /* processData */
+	UGRT_ST_TRACE_SHADOW,    /* mod_light_rckernel */
+	UGRT_ST_SHADE,           /* lambertian_shade / spot_shade / shadow_kernel */
+	UGRT_ST_REFLECT_GEN,     /* secondary ray generation (not in reference) */
+	UGRT_ST_TRACE_DDA,       /* 3D-DDA traversal (not in reference) */
+	UGRT_ST_ANIMATE,         /* copy_data_transform */
+	UGRT_ST_WORKLIST,        /* work-item list construction for the tracers */
+	UGRT_ST_COUNT
+};
+
+typedef struct ugrt_ctx ugrt_ctx;     /* device context */
+typedef struct ugrt_scene ugrt_scene; /* host scene = class Model, scene.h:13-57 */
+
+/* main.cu.h:1-42 turned into run-time parameters */
+typedef struct ugrt_config {
+	int width, height;       /* SCREEN_WIDTH, SCREEN_HEIGHT; multiples of tile */
+	int tile;                /* NUM_THREADS_X = NUM_THREADS_Y; must be 8 */
+	int slabs;               /* NUM_SLABS; must be 1 (main.cu.h:18) */
+	int light_nbx, light_nby; /* spherical light grid, 128 x 128 in the reference; even */
+	int row_begin, row_end;  /* tile rows [begin,end) this context renders (multi-GPU band);
+				    0, height/tile for the whole image */
+	unsigned flags;          /* UGRT_FLAG_* */
+	int uniform_dims[3];     /* cells of the uniform (reflection) grid */
+} ugrt_config;
+
+/* public members of class Camera, camera.h:19-35, plus the 64-float block of
+ * fillCoordinatesData, per_frame_funcs.h:18-39 */
+typedef struct ugrt_camera {
+	float worldori[4];
+	float modelview_matrix[16];
+	float projection_matrix[16];
+	float mvp_matrix[16];
+	float frustum_plane_eq[6][6];
+	float frustumcorner[8][3];
+	float camcoords[64];
+} ugrt_camera;
+
+/* outputs of FrustumGrid, frustum_grid.h:24-29 */
+typedef struct ugrt_grid_info {
+	unsigned *d_triangle_value_list; /* [total_refs] triangle ids, grouped by cell */
+	unsigned *d_triangle_key_list;   /* [total_refs] cell ids, ascending */
+	unsigned *d_span;                /* [num_cells] triangles per cell */
+	unsigned *d_offset;              /* [num_cells] exclusive scan of d_span */
+	unsigned total_refs;             /* "total_triangles", frustum_grid.h:254 */
+	unsigned num_cells;
+	unsigned cells_used;             /* "Number of actual cells", frustum_grid.h:337 */
+} ugrt_grid_info;
+
+/* ---- library ---------------------------------------------------------- */
+int ugrt_version(void);
+const char *ugrt_last_error(void);
+
+/* ---- host: scene I/O (scene.h, obj_parser/) --------------------------- */
+/* new Model(frames), scene.h:59 */
+int ugrt_scene_create(ugrt_scene **out);
+/* Model::some_material(char*), scene.h:370: positional material token file */
+int ugrt_scene_some_material(ugrt_scene *s, const char *file);
+/* Model::load_model(char*), scene.h:141 (static branch) -> objLoader::load,
+ * obj_parser/objLoader.cpp:5; the mtllib is opened relative to the cwd as in
+ * obj_parser.cpp:417 unless it is found next to the .obj first */
+int ugrt_scene_load_model(ugrt_scene *s, const char *path);
+/* Model::tmp_model(char*, int), scene.h:70: <dir>/f_<i>.obj, vertices only */
+int ugrt_scene_load_frame(ugrt_scene *s, const char *dir, int frame);
+int ugrt_scene_counts(const ugrt_scene *s, int *num_vertices, int *num_faces, int *num_materials);
+const float *ugrt_scene_vertexlist(const ugrt_scene *s);        /* h_vertexlist [3V] */
+const int *ugrt_scene_facelist(const ugrt_scene *s);            /* h_facelist [3F] */
+const int *ugrt_scene_materiallist_index(const ugrt_scene *s);  /* h_materiallist_index [F] */
+const float *ugrt_scene_materiallist(const ugrt_scene *s);      /* h_materiallist [6M] Ka,Kd */
+/* obj_material.reflect of the mtllib (obj_parser.h:53, token "r"), [mtl_count] */
+const float *ugrt_scene_reflectlist(const ugrt_scene *s, int *mtl_count);
+/* xMin..zMax, scene.h:43 */
+int ugrt_scene_bounds(const ugrt_scene *s, float bbmin[3], float bbmax[3]);
+void ugrt_scene_destroy(ugrt_scene *s);
+
+/* ---- host: camera (camera.h) ------------------------------------------ */
+/* setCameraCenter/LookAt/Up/setNearFar :13-16 + adjustCameraAndPosition :135 +
+ * getGLMatrices :86 + getFrustumProperties :115 + fillCoordinatesData's block.
+ * fovy in degrees (FOVY, main.cu.h:14), aspect = width/height. */
+int ugrt_camera_set(ugrt_camera *cam, const float eye[3], const float look[3], const float up[3],
+		    float near_plane, float far_plane, float fovy, float aspect);
+/* the 5x5x4 node table of setDirectionTexture, per_frame_funcs.h:161-419 */
+int ugrt_camera_direction_table(const float camcoords[64], float table[100]);
+
+/* writePPM(char*), per_app_funcs.h:39 (returns UGRT_EIO instead of exit(1)) */
+int ugrt_write_ppm(const char *path, int width, int height, const unsigned char *rgb);
+/* cosf/sinf of the animation angle as the library evaluates them */
+int ugrt_rot_cos_sin(float rot, float *c, float *s);
+
+/* ---- device: context --------------------------------------------------- */
+int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cfg);
+int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
+int ugrt_ctx_synchronize(ugrt_ctx *ctx);
+void ugrt_ctx_destroy(ugrt_ctx *ctx);
+
+/* fillCoordinatesData(), per_frame_funcs.h:18: makes `camcoords` the current
+ * camera block (dd_camcoords) and rebuilds the direction table (texdir) */
+int ugrt_upload_camera(ugrt_ctx *ctx, const float camcoords[64]);
+/* updateLightPosition(), per_frame_funcs.h:6: dd_light_position */
+int ugrt_set_light_position(ugrt_ctx *ctx, const float pos[3]);
+
+/* ---- device: grid build (frustum_grid.h) ------------------------------- */
+/* FrustumGrid::buildGrid(int*, float*), frustum_grid.h:210 */
+int ugrt_grid_build_perspective(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int num_faces);
+/* FrustumGrid::buildSphericalGrid(int*, float*, float, float), frustum_grid.h:368 */
+int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int num_faces,
+			      float xM, float yM);
+/* uniform world-space grid for the reflection bounce (README.md:1; no reference code) */
+int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int num_faces,
+			    const float bbmin[3], const float bbmax[3]);
+int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out);
+
+/* ---- device: tracing --------------------------------------------------- */
+/* FrustumTracer::trace(...), frustum_tracer.h:20-23 -> rckernel_alpha */
+int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
+		       const unsigned *d_offset, float *d_normal, float *d_t_value, float *d_ray_dir,
+		       int *d_shadowed, int *d_intersect_id, const float *d_vertlist, const int *d_trilist);
+/* getEffectiveRayGridMapping(...), per_frame_funcs.h:97 -> mapSort_Effective_kernel.
+ * d_map holds 2n entries, n = pixels of this context's band. */
+int ugrt_map_rays_to_light(ugrt_ctx *ctx, const float *d_t_value, const float *d_ray_dir, unsigned *d_map,
+			   const float *d_cam_position, float xM, float yM);
+/* processData(), per_frame_funcs.h:116: sorts d_map by light cell and writes the
+ * chunk start indices; *num_chunks = h_numCudaBlocks (decision_data.h:264).
+ * prefix_capacity entries must fit: n/64 + light cells + 1 always does. */
+int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity,
+		   unsigned *num_chunks);
+/* check_for_shadows(int), per_frame_funcs.h:139 -> mod_light_rckernel; same
+ * argument order as the kernel (light_kernel.cu:53) */
+int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, const float *d_vertlist,
+		      const int *d_trilist, const unsigned *d_span, const unsigned *d_offset,
+		      const float *d_t_value, const float *d_ray_dir, int *d_is_shadowed, const unsigned *d_map,
+		      const unsigned *d_prefix_map, const float *d_cam_position, unsigned num_chunks);
+
+/* ---- device: shading (shader.h:20-24) ---------------------------------- */
+int ugrt_shade_simple(ugrt_ctx *ctx, unsigned char *d_img, const float *d_normal, const float *d_t_value,
+		      const float *d_ray_dir, int *d_intersect_id, const float *d_cam_position,
+		      const int *d_mat_idx, const float *d_mat_list, int num_materials);
+int ugrt_shade_spotlight(ugrt_ctx *ctx, unsigned char *d_img, const float *d_normal, const float *d_t_value,
+			 const float *d_ray_dir, int *d_intersect_id, const float *d_cam_position,
+			 const int *d_mat_idx, const float *d_mat_list, int num_materials, float *d_dump);
+int ugrt_shade_add_shadows(ugrt_ctx *ctx, unsigned char *d_img, const int *d_is_shadowed);
+int ugrt_shade_perlin(ugrt_ctx *ctx, unsigned char *d_img, const float *d_t_value, const float *d_ray_dir,
+		      const float *d_cam_position, const int *d_intersect_id);
+
+/* ---- device: reflection bounce (not in the reference) ---- */
+/* secondary rays for hit pixels whose material has reflect > 0 */
+int ugrt_reflect_rays(ugrt_ctx *ctx, const float *d_cam_position, const float *d_t_value,
+		      const float *d_ray_dir, const int *d_intersect_id, const int *d_mat_idx,
+		      const float *d_reflect, int num_materials, const float *d_vertlist, const int *d_trilist,
+		      float eps, float *d_rays, int *d_active);
+/* Amanatides-Woo traversal of the context's uniform grid */
+int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
+		   const unsigned *d_offset, const float *d_vertlist, const int *d_trilist,
+		   const float *d_rays, const int *d_active, float *d_hit_t, int *d_hit_id);
+/* lambertian_shade + blend (1-k)*local + k*reflected */
+int ugrt_shade_reflect(ugrt_ctx *ctx, unsigned char *d_img, const float *d_normal, const float *d_t_value,
+		       const float *d_ray_dir, int *d_intersect_id, const float *d_cam_position,
+		       const int *d_mat_idx, const float *d_mat_list, const float *d_reflect, int num_materials,
+		       const float *d_vertlist, const int *d_trilist, const float *d_rays, const int *d_active,
+		       const float *d_hit_t, const int *d_hit_id);
+
+/* ---- device: animation (scene.h:122,336) -------------------------------- */
+/* Model::rotate_bunny(float) -> copy_data_transform, transformation_kernel.cu:4 */
+int ugrt_animate(ugrt_ctx *ctx, float *d_vertlist, const float *d_orig_list, int size, int offset,
+		 float rot_factor);
+
+/* ---- profiling ---------------------------------------------------------- */
+/* hipEvent pairs around every stage, on the context's stream */
+int ugrt_prof_enable(ugrt_ctx *ctx, int on);
+int ugrt_prof_reset(ugrt_ctx *ctx);
+/* total milliseconds and number of timed launches of a stage since the reset
+ * (synchronises the stream) */
+int ugrt_prof_get(ugrt_ctx *ctx, int stage, double *ms_total, int *launches);
+/* counters of the last tracer launches: [0] primary work items, [1] shadow
+ * work items, [2] shadow chunks traced */
+int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UGRT_H */

@@ -1475,7 +1475,8 @@ void orc_trace_dda(const float *g, const int *dims, const u32 *value_list, const
 				tdelta[k] = 3.0e38f;
 			}
 		}
-		while (!done) {
+		/* every step leaves a cell for good: dims[0]+dims[1]+dims[2] bounds the walk */
+		for (k = dims[0] + dims[1] + dims[2] + 3; k > 0 && !done; k--) {
 			u32 cell = (u32)((c[0] * dims[1] + c[1]) * dims[2] + c[2]);
 			u32 sp = span[cell], off = offset[cell], r;
 			int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
@@ -1496,7 +1497,7 @@ void orc_trace_dda(const float *g, const int *dims, const u32 *value_list, const
 				break;
 			}
 			c[ax] += step[ax];
-			if (c[ax] < 0 || c[ax] >= dims[ax])
+			if (step[ax] == 0 || c[ax] < 0 || c[ax] >= dims[ax])
 				break;
 			tmax[ax] += tdelta[ax];
 		}

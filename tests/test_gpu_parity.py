@@ -1,0 +1,314 @@
+"""GPU parity: every stage of the hot path through the C-ABI (libugrt.so, HIP on gfx950)
+against the CPU oracle on the same seeded inputs.  Integer / index outputs must be equal,
+float outputs bit-equal (both sides are IEEE fp32 without FMA contraction), colours equal
+as uint8 -- tighter than the 1e-4 the north star allows.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what):
+    a, b = bits(a), bits(b)
+    bad = np.flatnonzero(a != b)
+    assert bad.size == 0, "%s: %d of %d floats differ, first at %d" % (what, bad.size, a.size, bad[0])
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+SCENES = {}
+
+
+def scene(ugrt, name):
+    if name not in SCENES:
+        SCENES[name] = {"cornell": lambda: ugrt.scenes.cornell(), "hall": lambda: ugrt.scenes.hall(scale=0.1),
+                        "crash": lambda: ugrt.scenes.crash(scale=0.02)}[name]()
+    return SCENES[name]
+
+
+CASES = [
+    # scene, camera, W, H, light grid
+    ("cornell", "A", 256, 256, (128, 128)),
+    ("cornell", "B", 256, 256, (128, 128)),
+    ("hall", "ref", 256, 256, (64, 64)),
+    ("hall", "ref", 320, 200, (128, 128)),
+    ("crash", "ref", 256, 144, (128, 128)),
+]
+
+
+def setup_for(ugrt, s, cam):
+    return ugrt.FrameSetup(s["cameras"][cam], s["light_camera"], s["shading_light"])
+
+
+def make(ugrt, s, W, H, lg, rows=None, flags=0, udims=(32, 32, 16)):
+    ctx = ugrt.Context(W, H, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
+    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    return ctx, r
+
+
+@pytest.mark.parametrize("name,cam,W,H,lg", CASES)
+def test_perspective_grid_build(ugrt, O, torch, name, cam, W, H, lg):
+    s = scene(ugrt, name)
+    ctx, r = make(ugrt, s, W, H, lg)
+    c = ugrt.renderer.make_camera(s["cameras"][cam], 45.0, r.aspect)
+    ctx.upload_camera(c.camcoords)
+    ctx.grid_build_perspective(r.d_faces, r.d_verts, r.F)
+    value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
+    g = O.grid_perspective(O.cam_from(s["cameras"][cam], 45.0, r.aspect).cc, s["faces"], s["verts"], W // 8, H // 8)
+    assert gi.total_refs == g["R"] and gi.num_cells == (W // 8) * (H // 8) and gi.cells_used == g["used"]
+    np.testing.assert_array_equal(u32(key), g["keys"])
+    np.testing.assert_array_equal(u32(value), g["vals"])
+    np.testing.assert_array_equal(u32(span), g["span"])
+    np.testing.assert_array_equal(u32(offset), g["offset"])
+
+
+@pytest.mark.parametrize("name,cam,W,H,lg", CASES)
+def test_primary_trace_on_oracle_grid(ugrt, O, torch, name, cam, W, H, lg):
+    """HIP primary tracer consuming a CPU-built grid."""
+    s = scene(ugrt, name)
+    ctx, r = make(ugrt, s, W, H, lg)
+    ocam = O.cam_from(s["cameras"][cam], 45.0, r.aspect)
+    g = O.grid_perspective(ocam.cc, s["faces"], s["verts"], W // 8, H // 8)
+    want = O.trace_primary(ocam, W, H, g, s["verts"], s["faces"])
+    ctx.upload_camera(ocam.cc)
+    dv = ctx.upload(g["vals"].view(np.int32) if g["R"] else np.zeros(1, np.int32))
+    ds, do = ctx.upload(g["span"].view(np.int32)), ctx.upload(g["offset"].view(np.int32))
+    ctx.trace_primary(dv, ds, do, r.normal, r.t, r.dir, r.is_shadowed, r.intersect_id, r.d_verts, r.d_faces)
+    ctx.synchronize()
+    np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["id"])
+    assert_bits_equal(r.t.cpu().numpy(), want["t"], "t")
+    assert_bits_equal(r.dir.cpu().numpy(), want["dir"], "dir")
+    assert_bits_equal(r.normal.cpu().numpy(), want["normal"], "normal")
+    assert int(r.is_shadowed.abs().sum()) == 0
+    assert (want["id"] >= 0).sum() > 0
+
+
+@pytest.mark.parametrize("name,cam,W,H,lg", CASES)
+@pytest.mark.parametrize("all_chunks", [False, True])
+def test_full_frame(ugrt, O, torch, name, cam, W, H, lg, all_chunks):
+    """display() order end to end: grids, primary, mapping, ray sort, chunks, shadows, shading."""
+    s = scene(ugrt, name)
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS if all_chunks else 0
+    ctx, r = make(ugrt, s, W, H, lg, flags=flags)
+    setup = setup_for(ugrt, s, cam)
+    r.display(setup, frame_cnt=1, shadows=True)
+    ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, all_chunks=all_chunks)
+    pr = want["primary"]
+    np.testing.assert_array_equal(r.t.cpu().numpy().view(np.uint32), bits(pr["t"]))
+    assert_bits_equal(r.dir.cpu().numpy(), pr["dir"], "dir")
+    assert_bits_equal(r.normal.cpu().numpy(), pr["normal"], "normal")
+    # light grid
+    value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_SPHERICAL)
+    lg_want = want["lgrid"]
+    assert gi.total_refs == lg_want["R"]
+    np.testing.assert_array_equal(u32(key), lg_want["keys"])
+    np.testing.assert_array_equal(u32(value), lg_want["vals"])
+    np.testing.assert_array_equal(u32(span), lg_want["span"])
+    np.testing.assert_array_equal(u32(offset), lg_want["offset"])
+    # sorted rays + chunk starts
+    np.testing.assert_array_equal(u32(r.d_map), want["map"])
+    assert r.num_chunks == want["nchunks"]
+    np.testing.assert_array_equal(u32(r.prefix)[:r.num_chunks], want["prefix"][:want["nchunks"]])
+    # shadows, material ids, image
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"])
+    np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"])
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+    assert want["is_shadowed"].sum() > 0 and want["image"].max() > 0
+
+
+def test_spotlight_shading_frame2(ugrt, O, torch):
+    """frames >= 2 switch to spot_shade (main.cu:205-219)."""
+    s = scene(ugrt, "hall")
+    W, H, lg = 256, 256, (64, 64)
+    ctx, r = make(ugrt, s, W, H, lg)
+    setup = setup_for(ugrt, s, "ref")
+    r.display(setup, frame_cnt=2, shadows=True)
+    ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, frame_cnt=2)
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+    # the angle dump of spot_shade (shader.h:108-112)
+    ctx2, r2 = make(ugrt, s, W, H, lg)
+    r2.display(setup, frame_cnt=1, shadows=True, shade=False)
+    dump = ctx2.empty(2 * W * H, torch.float32)
+    ctx2.shade_spotlight(r2.image, r2.normal, r2.t, r2.dir, r2.intersect_id, r2.cam_pos, r2.d_matidx, r2.d_matlist,
+                         r2.num_materials, dump)
+    ctx2.synchronize()
+    img = np.zeros(3 * W * H, np.uint8)
+    odump = np.zeros(2 * W * H, np.float32)
+    ids = want["primary"]["id"].copy()
+    O.shade(want["lcam"].cc, setup.shading_light, img, want["primary"]["normal"], want["primary"]["t"],
+            want["primary"]["dir"], ids, want["cam"].worldori[:3], s["matidx"], s["mat_list"], 0, W * H, spot=True,
+            dump=odump)
+    assert_bits_equal(dump.cpu().numpy(), odump, "spot angle dump")
+    np.testing.assert_array_equal(r2.image.cpu().numpy(), img)
+
+
+def test_perlin_shade(ugrt, O, torch):
+    s = scene(ugrt, "cornell")
+    ctx, r = make(ugrt, s, 256, 256, (128, 128))
+    setup = setup_for(ugrt, s, "B")
+    r.display(setup, shadows=False, shade=False)
+    ctx.shade_perlin(r.image, r.t, r.dir, r.cam_pos, r.intersect_id)
+    ctx.synchronize()
+    img = np.zeros(3 * 256 * 256, np.uint8)
+    O.shade_perlin(img, r.intersect_id.cpu().numpy(), 256, 0, 256 * 256)
+    np.testing.assert_array_equal(r.image.cpu().numpy(), img)
+    assert img.max() > 0
+
+
+@pytest.mark.parametrize("name,cam,W,H", [("hall", "ref", 256, 256), ("crash", "ref", 256, 144)])
+def test_reflection_bounce(ugrt, O, torch, name, cam, W, H):
+    """uniform grid build + secondary rays + 3D-DDA + blended shading (no reference code: own spec)."""
+    s = scene(ugrt, name)
+    lg, ud = (64, 64), (32, 32, 16)
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    setup = setup_for(ugrt, s, cam)
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud)
+    value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_UNIFORM)
+    ug = want["ugrid"]
+    assert gi.total_refs == ug["R"]
+    np.testing.assert_array_equal(u32(key), ug["keys"])
+    np.testing.assert_array_equal(u32(value), ug["vals"])
+    np.testing.assert_array_equal(u32(span), ug["span"])
+    np.testing.assert_array_equal(u32(offset), ug["offset"])
+    np.testing.assert_array_equal(r.active.cpu().numpy(), want["active"])
+    assert_bits_equal(r.rays.cpu().numpy(), want["rays"], "secondary rays")
+    np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want["hit_id"])
+    assert_bits_equal(r.hit_t.cpu().numpy(), want["hit_t"], "dda t")
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+    assert want["active"].sum() > 100 and (want["hit_id"] >= 0).sum() > 100
+
+
+def test_animation(ugrt, O, torch):
+    """copy_data_transform (transformation_kernel.cu:4) then a rebuilt frame."""
+    s = scene(ugrt, "crash")
+    W, H, lg = 256, 144, (64, 64)
+    ctx, r = make(ugrt, s, W, H, lg)
+    r.init_orig_list(s["animated_size"], s["animated_offset"])
+    rot = 1.81 + 0.05 * 3
+    r.rotate_bunny(rot)
+    ctx.synchronize()
+    import ctypes
+
+    cr, sr = ctypes.c_float(), ctypes.c_float()
+    ugrt.lib.ugrt_rot_cos_sin(rot, ctypes.byref(cr), ctypes.byref(sr))
+    verts = np.ascontiguousarray(s["verts"], np.float32).reshape(-1).copy()
+    off, size = s["animated_offset"], s["animated_size"]
+    orig = verts[3 * off:3 * (off + size)].copy()
+    O.animate(verts, orig, size, off, cr.value, sr.value)
+    assert_bits_equal(r.d_verts.cpu().numpy(), verts, "animated vertices")
+    setup = setup_for(ugrt, s, "ref")
+    r.display(setup, shadows=True)
+    ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, verts=verts)
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+
+
+def test_band_split_equals_full_frame(ugrt, O, torch):
+    """Image-tile sharding (multi-GPU path): two contexts with complementary tile-row bands
+    produce exactly the full frame's primary outputs and the oracle's band results."""
+    s = scene(ugrt, "hall")
+    W, H, lg = 256, 256, (64, 64)
+    setup = setup_for(ugrt, s, "ref")
+    full_ctx, full = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS)
+    full.display(setup)
+    full_ctx.synchronize()
+    nby = H // 8
+    img = np.zeros(3 * W * H, np.uint8)
+    for rows in ((0, 13), (13, nby)):
+        ctx, r = make(ugrt, s, W, H, lg, rows=rows, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS)
+        r.display(setup)
+        ctx.synchronize()
+        want = O.frame(s, setup, W, H, rows=rows, light_grid=lg, all_chunks=True)
+        a, b = 3 * ctx.p0, 3 * (ctx.p0 + ctx.npix)
+        np.testing.assert_array_equal(r.image.cpu().numpy()[a:b], want["image"][a:b])
+        np.testing.assert_array_equal(r.is_shadowed.cpu().numpy()[ctx.p0:ctx.p0 + ctx.npix],
+                                      want["is_shadowed"][ctx.p0:ctx.p0 + ctx.npix])
+        _, _, _, _, gi = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
+        assert gi.total_refs == want["grid"]["R"]
+        img[a:b] = r.image.cpu().numpy()[a:b]
+    np.testing.assert_array_equal(img, full.image.cpu().numpy())
+
+
+def test_split_cells_merge(ugrt, O, torch):
+    """Cells with more than 256 triangles are split into segments merged by atomicMin; the
+    result must equal the sequential scan, including ties (coplanar duplicates)."""
+    rng = np.random.default_rng(7)
+    n = 3000
+    ctr = rng.uniform(-0.3, 0.3, size=(n, 1, 3)) + np.array([0, 0, -5.0])
+    tri = ctr + rng.normal(scale=0.25, size=(n, 3, 3))
+    verts = np.concatenate([tri.reshape(-1, 3), tri.reshape(-1, 3)[:300]]).astype(np.float32)  # 100 duplicates
+    faces = np.arange(len(verts)).reshape(-1, 3).astype(np.int32)
+    s = dict(verts=verts, faces=faces, matidx=np.zeros(len(faces), np.int32),
+             mat_list=np.array([[0.2, 0.2, 0.2, 0.8, 0.8, 0.8]], np.float32), reflect=np.zeros(1, np.float32))
+    cam = dict(eye=(0, 0, 0), look=(0, 0, -1), up=(0, 1, 0), near=0.1, far=100.0)
+    W = H = 64
+    ctx, r = make(ugrt, s, W, H, (16, 16))
+    ocam = O.cam_from(cam, 45.0, 1.0)
+    g = O.grid_perspective(ocam.cc, faces, verts, 8, 8)
+    assert g["span"].max() > 600
+    want = O.trace_primary(ocam, W, H, g, verts, faces)
+    for _ in range(2):  # twice: the merge slots must be re-armed
+        ctx.upload_camera(ocam.cc)
+        ctx.grid_build_perspective(r.d_faces, r.d_verts, r.F)
+        value, _, span, offset, _ = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
+        ctx.trace_primary(value, span, offset, r.normal, r.t, r.dir, r.is_shadowed, r.intersect_id, r.d_verts,
+                          r.d_faces)
+        ctx.synchronize()
+        np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["id"])
+        assert_bits_equal(r.t.cpu().numpy(), want["t"], "t")
+        assert_bits_equal(r.normal.cpu().numpy(), want["normal"], "normal")
+
+
+def test_known_answers_on_gpu(ugrt, torch):
+    """centre tile, one triangle at z=-5 -> 64/64 hits, t=5, n=(0,0,1), dir=(0,0,-1), id 0."""
+    verts = np.array([[-50, -50, -5], [50, -50, -5], [0, 50, -5]], np.float32)
+    faces = np.array([[0, 1, 2]], np.int32)
+    s = dict(verts=verts, faces=faces, matidx=np.zeros(1, np.int32),
+             mat_list=np.array([[0.2, 0.2, 0.2, 0.8, 0.8, 0.8]], np.float32), reflect=np.zeros(1, np.float32))
+    cam = dict(eye=(0, 0, 0), look=(0, 0, -1), up=(0, 1, 0), near=0.1, far=100.0)
+    W = H = 64
+    ctx, r = make(ugrt, s, W, H, (16, 16))
+    r.display(ugrt.FrameSetup(cam, cam, (0, 0, 0)), shadows=False)
+    ctx.synchronize()
+    ids = r.intersect_id.cpu().numpy().reshape(H, W)
+    t = r.t.cpu().numpy().reshape(H, W)
+    n = r.normal.cpu().numpy().reshape(H, W, 3)
+    d = r.dir.cpu().numpy().reshape(H, W, 3)
+    assert (ids == 0).all()  # material index after shading
+    assert abs(t[32, 32] - 5.0) < 1e-6 and np.allclose(d[32, 32], (0, 0, -1)) and np.allclose(n[32, 32], (0, 0, 1))
+    centre = t[28:36, 28:36]
+    assert (centre > 0).all() and np.allclose(centre * -d[28:36, 28:36, 2], 5.0, atol=1e-5)
+
+
+def test_error_paths(ugrt, torch):
+    with pytest.raises(ugrt.UgrtError) as e:
+        ugrt.Context(250, 256)
+    assert e.value.code == ugrt.UGRT_EINVAL
+    with pytest.raises(ugrt.UgrtError):
+        ugrt.Context(256, 256, rows=(5, 5))
+    with pytest.raises(ugrt.UgrtError):
+        ugrt.Context(256, 256, light_grid=(127, 128))
+    ctx = ugrt.Context(64, 64, light_grid=(16, 16))
+    with pytest.raises(ugrt.UgrtError):
+        ctx.grid_info(ugrt.GRID_UNIFORM)  # not built
+    with pytest.raises(ugrt.UgrtError):
+        ctx.grid_build_perspective(None, None, 3)

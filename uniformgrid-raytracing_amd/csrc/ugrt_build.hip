@@ -1,0 +1,369 @@
+// ugrt_build.hip -- triangle -> cell binning (grid construction).
+//
+// Reference pipeline (frustum_grid.h:210-366, same for :368-532):
+//   DSKernel -> [D2H + host z loop] -> cudppScan -> [D2H R] -> 4x cudaMalloc ->
+//   SlabKernel -> DSFillkernel -> cudppPlan + cudppSort(32 bit) -> do_scan_dump ->
+//   cudppPlan + cudppCompact -> [D2H] -> set_as_zero -> create_histogram -> cudppScan
+// Here: count (stores the cell range) -> rocPRIM inclusive scan -> [D2H R, 4 B]
+//   -> fill (one thread per REF, coalesced, no recomputation of the bbox) ->
+//   rocPRIM radix sort on ceil(log2 C) bits -> one boundary kernel -> one
+//   per-cell kernel -> rocPRIM exclusive scan.  Outputs are identical arrays:
+//   value[R], key[R], span[C], offset[C].
+// With NUM_SLABS = 1 the z-slab stage (SlabKernel, grid_kernel.cu:334, and the
+// host zMin/zMax loop, frustum_grid.h:221-241) always yields slab 0 and is
+// dropped.
+#include "ugrt_dev.h"
+
+// cell range of one triangle: {x0 | x1 << 16, y0 | y1 << 16, z0 | z1 << 16}
+struct Rng {
+	u32 x, y, z;
+};
+
+#define BUILD_THREADS 256
+
+// DSKernel, grid_kernel.cu:164-243 (+ the band clamp of the multi-GPU split)
+__global__ __launch_bounds__(BUILD_THREADS) void k_count_persp(CamBlock cam, const int *__restrict__ faces,
+								const float *__restrict__ verts, int F,
+								int gy_lo, int gy_hi, Rng *__restrict__ rng,
+								u32 *__restrict__ sizes)
+{
+	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (f >= F)
+		return;
+	int i1 = 3 * faces[f * 3 + 0], i2 = 3 * faces[f * 3 + 1], i3 = 3 * faces[f * 3 + 2];
+	float v1[3], v2[3], v3[3];
+	d_transformed_vertex(cam, verts[i1], verts[i1 + 1], verts[i1 + 2], v1);
+	d_transformed_vertex(cam, verts[i2], verts[i2 + 1], verts[i2 + 2], v2);
+	d_transformed_vertex(cam, verts[i3], verts[i3 + 1], verts[i3 + 2], v3);
+	float xmin = d_min3(v1[0], v2[0], v3[0]);
+	float ymin = d_min3(v1[1], v2[1], v3[1]);
+	float xmax = d_max3(v1[0], v2[0], v3[0]);
+	float ymax = d_max3(v1[1], v2[1], v3[1]);
+	int nbx = cam.nbx, nby = cam.nby;
+	int gxmin = ugrt_floor2i(((xmin + 1.0f) / 2.0f) * (float)nbx);
+	int gymin = ugrt_floor2i(((ymin + 1.0f) / 2.0f) * (float)nby);
+	int gxmax = ugrt_floor2i(((xmax + 1.0f) / 2.0f) * (float)nbx);
+	int gymax = ugrt_floor2i(((ymax + 1.0f) / 2.0f) * (float)nby);
+	gxmin = d_clampi(gxmin, 0, nbx - 1);
+	gymin = d_clampi(gymin, 0, nby - 1);
+	gxmax = d_clampi(gxmax, 0, nbx - 1);
+	gymax = d_clampi(gymax, 0, nby - 1);
+	u32 size = 0;
+	if (!(gymax < gy_lo || gymin >= gy_hi)) {
+		gymin = gymin < gy_lo ? gy_lo : gymin;
+		gymax = gymax > gy_hi - 1 ? gy_hi - 1 : gymax;
+		size = (u32)((gxmax - gxmin + 1) * (gymax - gymin + 1));
+	}
+	Rng r;
+	r.x = (u32)gxmin | ((u32)gxmax << 16);
+	r.y = (u32)gymin | ((u32)gymax << 16);
+	r.z = 0;
+	rng[f] = r;
+	sizes[f] = size;
+}
+
+// DS_spherical_Kernel, grid_kernel.cu:481-659
+__global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const int *__restrict__ faces,
+							      const float *__restrict__ verts, int F, int lnbx,
+							      int lnby, float xM, float yM, Rng *__restrict__ rng,
+							      u32 *__restrict__ sizes)
+{
+	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (f >= F)
+		return;
+	int blx[3], bly[3];
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		int idx = 3 * faces[f * 3 + k];
+		float point[3];
+		point[0] = verts[idx + 0] - cam.cc[0];
+		point[1] = verts[idx + 1] - cam.cc[1];
+		point[2] = verts[idx + 2] - cam.cc[2];
+		float radius = d_magnitude(point);
+		point[0] /= radius;
+		point[1] /= radius;
+		point[2] /= radius;
+		blx[k] = (int)d_effective_x(cam, point, xM, lnbx / 2);
+		bly[k] = (int)d_effective_y(cam, point, yM, lnby / 2);
+	}
+	int gxmin = d_clampi(d_imin3(blx[0], blx[1], blx[2]), 0, lnbx - 1);
+	int gymin = d_clampi(d_imin3(bly[0], bly[1], bly[2]), 0, lnby - 1);
+	int gxmax = d_clampi(d_imax3(blx[0], blx[1], blx[2]), 0, lnbx - 1);
+	int gymax = d_clampi(d_imax3(bly[0], bly[1], bly[2]), 0, lnby - 1);
+	Rng r;
+	r.x = (u32)gxmin | ((u32)gxmax << 16);
+	r.y = (u32)gymin | ((u32)gymax << 16);
+	r.z = 0;
+	rng[f] = r;
+	sizes[f] = (u32)((gxmax - gxmin + 1) * (gymax - gymin + 1));
+}
+
+struct UGrid {
+	float lo[3], cs[3], inv[3];
+	int dims[3];
+};
+
+__device__ __forceinline__ int d_ucell(const UGrid &g, int k, float p)
+{
+	int c = ugrt_floor2i((p - g.lo[k]) * g.inv[k]);
+	return d_clampi(c, 0, g.dims[k] - 1);
+}
+
+// uniform grid: world-space bbox -> 3-D cell range
+__global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const int *__restrict__ faces,
+								  const float *__restrict__ verts, int F,
+								  Rng *__restrict__ rng, u32 *__restrict__ sizes)
+{
+	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (f >= F)
+		return;
+	int i1 = 3 * faces[f * 3 + 0], i2 = 3 * faces[f * 3 + 1], i3 = 3 * faces[f * 3 + 2];
+	u32 packed[3], size = 1;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		float a = verts[i1 + k], b = verts[i2 + k], c = verts[i3 + k];
+		int lo = d_ucell(g, k, d_min3(a, b, c));
+		int hi = d_ucell(g, k, d_max3(a, b, c));
+		packed[k] = (u32)lo | ((u32)hi << 16);
+		size *= (u32)(hi - lo + 1);
+	}
+	Rng r;
+	r.x = packed[0];
+	r.y = packed[1];
+	r.z = packed[2];
+	rng[f] = r;
+	sizes[f] = size;
+}
+
+// DSFillkernel (grid_kernel.cu:245-332) inverted: one thread per reference.
+// ref r belongs to the triangle f with scan[f-1] <= r < scan[f]; its position
+// inside the triangle's box is x-major, then y, then z (:318-325), and
+// key = ((gx*ny + gy)*nz + gz).  Writes are fully coalesced and the work per
+// thread no longer depends on how many cells a triangle covers (border cells
+// collect thousands: SURVEY.md Q9).
+__global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
+							 int F, u32 R, int ny, int nz, u32 *__restrict__ keys,
+							 u32 *__restrict__ vals)
+{
+	u32 r = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (r >= R)
+		return;
+	int lo = 0, hi = F - 1; // smallest f with scan[f] > r
+	while (lo < hi) {
+		int mid = (lo + hi) >> 1;
+		if (scan[mid] > r)
+			hi = mid;
+		else
+			lo = mid + 1;
+	}
+	int f = lo;
+	u32 base = f ? scan[f - 1] : 0;
+	u32 local = r - base;
+	Rng g = rng[f];
+	u32 x0 = g.x & 0xFFFFu, y0 = g.y & 0xFFFFu, y1 = g.y >> 16, z0 = g.z & 0xFFFFu, z1 = g.z >> 16;
+	u32 sy = y1 - y0 + 1, sz = z1 - z0 + 1;
+	u32 k = local % sz;
+	u32 ij = local / sz;
+	u32 j = ij % sy;
+	u32 i = ij / sy;
+	keys[r] = ((x0 + i) * (u32)ny + (y0 + j)) * (u32)nz + (z0 + k);
+	vals[r] = (u32)f;
+}
+
+// do_scan_dump + cudppCompact + create_histogram (misc_kernel.cu:4-60,
+// frustum_grid.h:334) in one pass over the sorted keys: run heads record the
+// run start, run tails the run end; used[0] counts the runs.
+__global__ __launch_bounds__(BUILD_THREADS) void k_bounds(const u32 *__restrict__ keys, u32 R,
+							   u32 *__restrict__ cstart, u32 *__restrict__ cend,
+							   u32 *__restrict__ used)
+{
+	u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (i >= R)
+		return;
+	u32 k = keys[i];
+	bool head = (i == 0) || (keys[i - 1] != k);
+	bool tail = (i == R - 1) || (keys[i + 1] != k);
+	if (head) {
+		cstart[k] = i;
+		atomicAdd(used, 1u);
+	}
+	if (tail)
+		cend[k] = i + 1;
+}
+
+// span = run length (0 for cells without a run: set_as_zero, misc_kernel.cu:26)
+__global__ __launch_bounds__(BUILD_THREADS) void k_span(const u32 *__restrict__ cstart, u32 *__restrict__ span_io,
+							 u32 C)
+{
+	u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (c >= C)
+		return;
+	span_io[c] = span_io[c] - cstart[c]; // span_io holds the run end on entry
+}
+
+static int bits_for(u32 C)
+{
+	int b = 1;
+	while (b < 32 && (1ull << b) < (unsigned long long)C)
+		b++;
+	return b;
+}
+
+// shared tail of the three builders: sizes/rng are filled, ny/nz give the key layout
+static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz)
+{
+	hipStream_t st = ctx->stream;
+	int rc;
+	G.valid = false;
+	G.C = C;
+	if ((rc = ugrt_buf_reserve(ctx, G.scan, (size_t)F * 4)))
+		return rc;
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SCAN);
+	rc = ugrt_prim_inclusive_scan(ctx, (const u32 *)G.sizes.p, (u32 *)G.scan.p, (size_t)F);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_SCAN);
+	if (rc)
+		return rc;
+	// total_triangles, frustum_grid.h:254 (the one unavoidable read-back: it sizes the lists)
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned, (u32 *)G.scan.p + (F - 1), 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipStreamSynchronize(st));
+	u32 R = ctx->h_pinned[0];
+	G.R = R;
+	size_t rb = (size_t)(R ? R : 1) * 4;
+	for (int i = 0; i < 2; i++) {
+		if ((rc = ugrt_buf_reserve(ctx, G.key[i], rb)))
+			return rc;
+		if ((rc = ugrt_buf_reserve(ctx, G.val[i], rb)))
+			return rc;
+	}
+	if ((rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 4)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, G.offset, (size_t)C * 4)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, G.cstart, (size_t)C * 4)))
+		return rc;
+	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
+	if (R) {
+		ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
+		hipLaunchKernelGGL(k_fill, dim3((R + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   (const u32 *)G.scan.p, (const Rng *)G.rng.p, F, R, ny, nz, k0, v0);
+		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
+		UGRT_HIP(hipGetLastError());
+		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
+		rc = ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, R, bits_for(C));
+		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
+		if (rc)
+			return rc;
+	}
+	G.keys = k1;
+	G.vals = v1;
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
+	UGRT_HIP(hipMemsetAsync(G.span.p, 0, (size_t)C * 4, st));
+	UGRT_HIP(hipMemsetAsync(G.cstart.p, 0, (size_t)C * 4, st));
+	UGRT_HIP(hipMemsetAsync(ctx->d_small, 0, 4, st));
+	if (R) {
+		hipLaunchKernelGGL(k_bounds, dim3((R + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   (const u32 *)k1, R, (u32 *)G.cstart.p, (u32 *)G.span.p, ctx->d_small);
+		UGRT_HIP(hipGetLastError());
+		hipLaunchKernelGGL(k_span, dim3((C + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   (const u32 *)G.cstart.p, (u32 *)G.span.p, C);
+		UGRT_HIP(hipGetLastError());
+	}
+	rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
+	if (rc)
+		return rc;
+	// "Number of actual cells" (frustum_grid.h:337): fetched lazily by ugrt_grid_get_info
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + (&G - ctx->grid), ctx->d_small, 4, hipMemcpyDeviceToHost, st));
+	G.valid = true;
+	return UGRT_OK;
+}
+
+static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const float *d_vertlist, int F,
+			  const char *who)
+{
+	if (!ctx || !d_facelist || !d_vertlist)
+		return ugrt_fail(UGRT_EINVAL, "%s: null argument", who);
+	if (F <= 0)
+		return ugrt_fail(UGRT_EINVAL, "%s: num_faces must be positive", who);
+	UGRT_HIP(hipSetDevice(ctx->device));
+	int rc;
+	if ((rc = ugrt_buf_reserve(ctx, G.rng, (size_t)F * sizeof(Rng))))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, G.sizes, (size_t)F * 4)))
+		return rc;
+	return UGRT_OK;
+}
+
+// FrustumGrid::buildGrid, frustum_grid.h:210
+extern "C" int ugrt_grid_build_perspective(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int F)
+{
+	Grid &G = ctx->grid[UGRT_GRID_PERSPECTIVE];
+	int rc = build_prologue(ctx, G, d_facelist, d_vertlist, F, "grid_build_perspective");
+	if (rc)
+		return rc;
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
+	hipLaunchKernelGGL(k_count_persp, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
+			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, ctx->cfg.row_begin, ctx->cfg.row_end,
+			   (Rng *)G.rng.p, (u32 *)G.sizes.p);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
+	UGRT_HIP(hipGetLastError());
+	G.dims[0] = ctx->nbx;
+	G.dims[1] = ctx->nby;
+	G.dims[2] = 1;
+	return build_common(ctx, G, F, (u32)ctx->nbx * (u32)ctx->nby, ctx->nby, 1);
+}
+
+// FrustumGrid::buildSphericalGrid, frustum_grid.h:368
+extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int F,
+					 float xM, float yM)
+{
+	Grid &G = ctx->grid[UGRT_GRID_SPHERICAL];
+	int rc = build_prologue(ctx, G, d_facelist, d_vertlist, F, "grid_build_spherical");
+	if (rc)
+		return rc;
+	int lx = ctx->cfg.light_nbx, ly = ctx->cfg.light_nby;
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
+	hipLaunchKernelGGL(k_count_sph, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
+			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, lx, ly, xM, yM, (Rng *)G.rng.p,
+			   (u32 *)G.sizes.p);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
+	UGRT_HIP(hipGetLastError());
+	G.dims[0] = lx;
+	G.dims[1] = ly;
+	G.dims[2] = 1;
+	return build_common(ctx, G, F, (u32)lx * (u32)ly, ly, 1);
+}
+
+// uniform grid over the scene box (Model::{x,y,z}{Min,Max}, scene.h:273-292),
+// padded by 1e-4 of the extent + 1e-4 so that no vertex lies on the boundary
+extern "C" int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int F,
+				       const float bbmin[3], const float bbmax[3])
+{
+	if (!bbmin || !bbmax)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_uniform: null bounds");
+	Grid &G = ctx->grid[UGRT_GRID_UNIFORM];
+	int rc = build_prologue(ctx, G, d_facelist, d_vertlist, F, "grid_build_uniform");
+	if (rc)
+		return rc;
+	UGrid g;
+	for (int k = 0; k < 3; k++) {
+		float ext = bbmax[k] - bbmin[k];
+		float pad = ext * 1e-4f + 1e-4f;
+		float lo = bbmin[k] - pad, hi = bbmax[k] + pad;
+		float cs = (hi - lo) / (float)ctx->cfg.uniform_dims[k];
+		g.lo[k] = lo;
+		g.cs[k] = cs;
+		g.inv[k] = 1.0f / cs;
+		g.dims[k] = ctx->cfg.uniform_dims[k];
+		G.dims[k] = g.dims[k];
+		G.ug[k] = lo;
+		G.ug[3 + k] = cs;
+		G.ug[6 + k] = g.inv[k];
+	}
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
+	hipLaunchKernelGGL(k_count_uniform, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
+			   ctx->stream, g, d_facelist, d_vertlist, F, (Rng *)G.rng.p, (u32 *)G.sizes.p);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
+	UGRT_HIP(hipGetLastError());
+	return build_common(ctx, G, F, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], g.dims[1], g.dims[2]);
+}

@@ -1,0 +1,314 @@
+// ugrt_context.hip -- device context: buffers, stream, camera block, profiler.
+//
+// The reference keeps this state in globals and per-class members
+// (main.cu.h:58-63, frustum_grid.h:31-66, decision_data.h:13-40) and
+// re-allocates the ref-sized lists on every build (frustum_grid.h:260-272).
+// Here one context owns grow-only device buffers; nothing is allocated in the
+// steady state of a frame loop.
+#include "ugrt_ctx.h"
+
+static int check_device(int device)
+{
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return ugrt_fail(UGRT_ENODEV, "no HIP device available (%s); libugrt has no CPU fallback",
+				 e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+	if (device < 0 || device >= n)
+		return ugrt_fail(UGRT_EINVAL, "device %d out of range (%d devices)", device, n);
+	return UGRT_OK;
+}
+
+int ugrt_buf_reserve(ugrt_ctx *ctx, DevBuf &b, size_t bytes)
+{
+	(void)ctx;
+	if (bytes <= b.cap && b.p)
+		return UGRT_OK;
+	size_t want = bytes + bytes / 2;
+	if (want < 256)
+		want = 256;
+	void *np = nullptr;
+	hipError_t e = hipMalloc(&np, want);
+	if (e != hipSuccess)
+		return ugrt_fail(UGRT_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+	if (b.p) {
+		// the old buffer may still be in use by enqueued work
+		(void)hipStreamSynchronize(ctx->stream);
+		(void)hipFree(b.p);
+	}
+	b.p = np;
+	b.cap = want;
+	return UGRT_OK;
+}
+
+static void buf_free(DevBuf &b)
+{
+	if (b.p)
+		(void)hipFree(b.p);
+	b.p = nullptr;
+	b.cap = 0;
+}
+
+extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cfg)
+{
+	if (!out || !cfg)
+		return ugrt_fail(UGRT_EINVAL, "ctx_create: null argument");
+	int rc = check_device(device);
+	if (rc)
+		return rc;
+	if (cfg->tile != 8)
+		return ugrt_fail(UGRT_EINVAL, "tile must be 8 (one 8x8 tile = one wavefront; main.cu.h:25-26)");
+	if (cfg->slabs != 1)
+		return ugrt_fail(UGRT_EINVAL, "slabs must be 1 (NUM_SLABS, main.cu.h:18)");
+	if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % 8 || cfg->height % 8)
+		return ugrt_fail(UGRT_EINVAL, "width and height must be positive multiples of 8");
+	int nbx = cfg->width / 8, nby = cfg->height / 8;
+	if (nbx > 65535 || nby > 65535)
+		return ugrt_fail(UGRT_EINVAL, "image too large");
+	if (cfg->row_begin < 0 || cfg->row_end > nby || cfg->row_begin >= cfg->row_end)
+		return ugrt_fail(UGRT_EINVAL, "row band [%d,%d) outside [0,%d)", cfg->row_begin, cfg->row_end, nby);
+	if (cfg->light_nbx < 2 || cfg->light_nby < 2 || (cfg->light_nbx & 1) || (cfg->light_nby & 1) ||
+	    cfg->light_nbx > 4096 || cfg->light_nby > 4096)
+		return ugrt_fail(UGRT_EINVAL, "light grid must be even and within [2,4096]^2");
+	for (int k = 0; k < 3; k++)
+		if (cfg->uniform_dims[k] < 1 || cfg->uniform_dims[k] > 1024)
+			return ugrt_fail(UGRT_EINVAL, "uniform_dims[%d] must be within [1,1024]", k);
+	UGRT_HIP(hipSetDevice(device));
+	ugrt_ctx *ctx = new ugrt_ctx();
+	ctx->cfg = *cfg;
+	ctx->device = device;
+	ctx->nbx = nbx;
+	ctx->nby = nby;
+	ctx->p0 = cfg->row_begin * 8 * cfg->width;
+	ctx->npix = (cfg->row_end - cfg->row_begin) * 8 * cfg->width;
+	memset(&ctx->cam, 0, sizeof(ctx->cam));
+	ctx->cam.W = cfg->width;
+	ctx->cam.H = cfg->height;
+	ctx->cam.nbx = nbx;
+	ctx->cam.nby = nby;
+	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 16 * sizeof(u32), hipHostMallocDefault);
+	if (e == hipSuccess)
+		e = hipMalloc((void **)&ctx->d_small, (16 + 100) * sizeof(u32));
+	if (e != hipSuccess) {
+		ugrt_ctx_destroy(ctx);
+		return ugrt_fail(UGRT_EHIP, "ctx_create: %s", hipGetErrorString(e));
+	}
+	// per-pixel (t,ref) merge slots of split cells: all ones = "no hit"
+	rc = ugrt_buf_reserve(ctx, ctx->best, (size_t)ctx->npix * sizeof(u64));
+	if (!rc) {
+		e = hipMemset(ctx->best.p, 0xFF, (size_t)ctx->npix * sizeof(u64));
+		if (e != hipSuccess)
+			rc = ugrt_fail(UGRT_EHIP, "ctx_create: %s", hipGetErrorString(e));
+	}
+	if (rc) {
+		ugrt_ctx_destroy(ctx);
+		return rc;
+	}
+	*out = ctx;
+	return UGRT_OK;
+}
+
+extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	for (int g = 0; g < 3; g++) {
+		Grid &G = ctx->grid[g];
+		buf_free(G.rng);
+		buf_free(G.sizes);
+		buf_free(G.scan);
+		buf_free(G.key[0]);
+		buf_free(G.key[1]);
+		buf_free(G.val[0]);
+		buf_free(G.val[1]);
+		buf_free(G.span);
+		buf_free(G.offset);
+		buf_free(G.cstart);
+	}
+	buf_free(ctx->temp);
+	buf_free(ctx->witems);
+	buf_free(ctx->wcount);
+	buf_free(ctx->wscan);
+	buf_free(ctx->best);
+	buf_free(ctx->rmap[0]);
+	buf_free(ctx->rmap[1]);
+	buf_free(ctx->rspan);
+	buf_free(ctx->roffset);
+	buf_free(ctx->rstart);
+	buf_free(ctx->cchunks);
+	buf_free(ctx->cbase);
+	if (ctx->h_pinned)
+		(void)hipHostFree(ctx->h_pinned);
+	if (ctx->d_small)
+		(void)hipFree(ctx->d_small);
+	for (int s = 0; s < UGRT_ST_COUNT; s++)
+		for (auto &p : ctx->prof[s]) {
+			(void)hipEventDestroy(p.a);
+			(void)hipEventDestroy(p.b);
+		}
+	for (auto &p : ctx->prof_pool) {
+		(void)hipEventDestroy(p.a);
+		(void)hipEventDestroy(p.b);
+	}
+	delete ctx;
+}
+
+extern "C" int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream)
+{
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "set_stream: null ctx");
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	ctx->stream = (hipStream_t)hip_stream;
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_ctx_synchronize(ugrt_ctx *ctx)
+{
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "synchronize: null ctx");
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	return UGRT_OK;
+}
+
+// the direction table travels as a by-value kernel argument and is written to
+// device memory in stream order, so back-to-back camera changes cannot race
+struct TexArg {
+	float v[100];
+};
+__global__ void k_store_table(TexArg t, float *dst)
+{
+	int i = threadIdx.x;
+	if (i < 100)
+		dst[i] = t.v[i];
+}
+
+float *ugrt_ctx_tex(ugrt_ctx *ctx) { return (float *)(ctx->d_small + 16); }
+
+// per_frame_funcs.h:18-43 fillCoordinatesData (+ setDirectionTexture :161)
+extern "C" int ugrt_upload_camera(ugrt_ctx *ctx, const float camcoords[64])
+{
+	if (!ctx || !camcoords)
+		return ugrt_fail(UGRT_EINVAL, "upload_camera: null argument");
+	memcpy(ctx->cam.cc, camcoords, sizeof(float) * 64);
+	TexArg t;
+	int rc = ugrt_camera_direction_table(camcoords, t.v);
+	if (rc)
+		return rc;
+	memcpy(ctx->cam.tex, t.v, sizeof(t.v));
+	UGRT_HIP(hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(k_store_table, dim3(1), dim3(128), 0, ctx->stream, t, ugrt_ctx_tex(ctx));
+	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}
+
+// per_frame_funcs.h:6-16 updateLightPosition
+extern "C" int ugrt_set_light_position(ugrt_ctx *ctx, const float pos[3])
+{
+	if (!ctx || !pos)
+		return ugrt_fail(UGRT_EINVAL, "set_light_position: null argument");
+	ctx->cam.light[0] = pos[0];
+	ctx->cam.light[1] = pos[1];
+	ctx->cam.light[2] = pos[2];
+	ctx->cam.light[3] = 0.0f;
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out)
+{
+	if (!ctx || !out || which < 0 || which > 2)
+		return ugrt_fail(UGRT_EINVAL, "grid_get_info: bad argument");
+	Grid &G = ctx->grid[which];
+	if (!G.valid)
+		return ugrt_fail(UGRT_EINVAL, "grid_get_info: grid %d has not been built", which);
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	out->d_triangle_value_list = G.vals;
+	out->d_triangle_key_list = G.keys;
+	out->d_span = (unsigned *)G.span.p;
+	out->d_offset = (unsigned *)G.offset.p;
+	out->total_refs = G.R;
+	out->num_cells = G.C;
+	out->cells_used = ctx->h_pinned[4 + which];
+	return UGRT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// profiler: hipEvent pairs on the context's stream
+// ---------------------------------------------------------------------------
+void ugrt_prof_begin(ugrt_ctx *ctx, int stage)
+{
+	if (!ctx->prof_on)
+		return;
+	ProfPair p;
+	if (!ctx->prof_pool.empty()) {
+		p = ctx->prof_pool.back();
+		ctx->prof_pool.pop_back();
+	} else {
+		if (hipEventCreate(&p.a) != hipSuccess)
+			return;
+		if (hipEventCreate(&p.b) != hipSuccess) {
+			(void)hipEventDestroy(p.a);
+			return;
+		}
+	}
+	(void)hipEventRecord(p.a, ctx->stream);
+	ctx->prof[stage].push_back(p);
+}
+
+void ugrt_prof_end(ugrt_ctx *ctx, int stage)
+{
+	if (!ctx->prof_on || ctx->prof[stage].empty())
+		return;
+	(void)hipEventRecord(ctx->prof[stage].back().b, ctx->stream);
+}
+
+extern "C" int ugrt_prof_enable(ugrt_ctx *ctx, int on)
+{
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "prof_enable: null ctx");
+	ctx->prof_on = on != 0;
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_prof_reset(ugrt_ctx *ctx)
+{
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "prof_reset: null ctx");
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	for (int s = 0; s < UGRT_ST_COUNT; s++) {
+		for (auto &p : ctx->prof[s])
+			ctx->prof_pool.push_back(p);
+		ctx->prof[s].clear();
+	}
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_prof_get(ugrt_ctx *ctx, int stage, double *ms_total, int *launches)
+{
+	if (!ctx || stage < 0 || stage >= UGRT_ST_COUNT)
+		return ugrt_fail(UGRT_EINVAL, "prof_get: bad argument");
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	double tot = 0.0;
+	int n = 0;
+	for (auto &p : ctx->prof[stage]) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+			tot += ms;
+			n++;
+		}
+	}
+	if (ms_total)
+		*ms_total = tot;
+	if (launches)
+		*launches = n;
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8])
+{
+	if (!ctx || !stats)
+		return ugrt_fail(UGRT_EINVAL, "stats_get: null argument");
+	memcpy(stats, ctx->stats, sizeof(ctx->stats));
+	return UGRT_OK;
+}

@@ -1,0 +1,83 @@
+// ugrt_ctx.h -- device context of libugrt.so (HIP translation units only)
+#ifndef UGRT_CTX_H
+#define UGRT_CTX_H
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "ugrt_internal.h"
+
+// The reference keeps the camera in __constant__ dd_camcoords[64], the light in
+// dd_light_position[6] and the ray targets in a 5x5 texture (main.cu.h:58-63).
+// Here the whole block (688 B) is a by-value kernel argument: it lives in the
+// kernarg segment and is read with scalar loads into SGPRs.
+struct CamBlock {
+	float cc[64];   // dd_camcoords
+	float tex[100]; // texdir nodes, [5][5][4]
+	float light[4]; // dd_light_position[0..2]
+	int W, H, nbx, nby;
+};
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct Grid {
+	DevBuf rng, sizes, scan;          // per triangle
+	DevBuf key[2], val[2];            // per ref, ping-pong for the radix sort
+	DevBuf span, offset, cstart;      // per cell
+	u32 *keys = nullptr, *vals = nullptr; // sorted result (one of key[i]/val[i])
+	u32 R = 0, C = 0, cells_used = 0;
+	int dims[3] = { 0, 0, 0 };
+	float ug[12] = { 0 }; // uniform grid: lo[3], cell[3], inv cell[3]
+	bool valid = false;
+};
+
+struct ProfPair {
+	hipEvent_t a, b;
+};
+
+struct ugrt_ctx {
+	ugrt_config cfg;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	CamBlock cam;
+	int nbx = 0, nby = 0; // screen grid
+	int p0 = 0, npix = 0; // first pixel and pixel count of this context's band
+	Grid grid[3];
+	DevBuf temp;                  // rocPRIM temporary storage
+	DevBuf witems, wcount, wscan; // tracer work lists
+	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
+	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)
+	DevBuf rspan, roffset, rstart, cchunks, cbase; // ray runs per light cell
+	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
+	u32 *d_small = nullptr;       // 16 u32 of device scratch (totals)
+	bool prof_on = false;
+	std::vector<ProfPair> prof[UGRT_ST_COUNT];
+	std::vector<ProfPair> prof_pool;
+	unsigned long long stats[8] = { 0 };
+};
+
+#define UGRT_HIP(call)                                                                            \
+	do {                                                                                      \
+		hipError_t e_ = (call);                                                           \
+		if (e_ != hipSuccess)                                                             \
+			return ugrt_fail(UGRT_EHIP, "%s:%d %s -> %s", __FILE__, __LINE__, #call, \
+					 hipGetErrorString(e_));                                  \
+	} while (0)
+
+int ugrt_buf_reserve(ugrt_ctx *ctx, DevBuf &b, size_t bytes);
+float *ugrt_ctx_tex(ugrt_ctx *ctx); // device copy of the 5x5x4 direction table
+void ugrt_prof_begin(ugrt_ctx *ctx, int stage);
+void ugrt_prof_end(ugrt_ctx *ctx, int stage);
+
+// rocPRIM wrappers (ugrt_prims.hip); all enqueue on ctx->stream
+int ugrt_prim_inclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
+int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
+// stable LSD radix sort of (key,value) pairs on key bits [0,end_bit)
+int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
+			 int end_bit);
+
+#endif

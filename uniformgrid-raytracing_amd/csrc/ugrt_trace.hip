@@ -1,0 +1,621 @@
+// ugrt_trace.hip -- the three tracers: primary (perspective grid), shadow
+// (spherical light grid) and reflection (uniform grid, 3D-DDA).
+//
+// Mapping to CDNA4: the reference's 8x8-thread CUDA block per grid tile
+// (trace_kernel.cu:84, light_kernel.cu:52) is exactly one 64-lane wavefront,
+// so "block per cell" becomes "wave per work item" with no multi-wave
+// barriers.  A work item is (cell, run of <= SEG triangles of that cell): the
+// reference gives a whole cell to one block, and border cells that collect
+// every clamped off-screen triangle then serialise the frame;
+// here long cells are cut into segments that run on different waves and are
+// merged with a 64-bit atomicMin on (t bits << 32 | ref index), which keeps the
+// reference's tie-break (strict `<`, first ref in the sorted list wins,
+// trace_kernel.cu:38).  Triangles are staged through LDS 64 at a time by the
+// wave itself (trace_kernel.cu:151-175) and read back as LDS broadcasts.
+// Waves are persistent: the launch is sized to the chip and each wave strides
+// over the work list, whose length stays on the device.
+#include "ugrt_dev.h"
+
+#define SEG 256u          // triangles per work item
+#define TRI_STRIDE 12     // floats per staged triangle (9 used, 48 B: ds_read_b128 x3)
+#define WL_THREADS 256
+
+struct WItem {
+	u32 cell;  // primary: screen cell; shadow: chunk index
+	u32 begin; // first ref
+	u32 count; // refs in this item (<= SEG)
+	u32 multi; // primary: cell is split across items
+};
+
+// ---------------------------------------------------------------------------
+// work lists
+// ---------------------------------------------------------------------------
+// primary: one entry per cell of the band, x-major like the cell ids
+__global__ __launch_bounds__(WL_THREADS) void k_wl_count_primary(const u32 *__restrict__ span, int nby, int gy_lo,
+								  int rows, u32 ncell, u32 *__restrict__ cnt)
+{
+	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (i >= ncell)
+		return;
+	u32 cell = (i / (u32)rows) * (u32)nby + (u32)gy_lo + (i % (u32)rows);
+	u32 sp = span[cell];
+	cnt[i] = sp ? (sp + SEG - 1) / SEG : 1u;
+}
+
+__global__ __launch_bounds__(WL_THREADS) void k_wl_fill_primary(const u32 *__restrict__ span,
+								 const u32 *__restrict__ offset, int nby, int gy_lo,
+								 int rows, u32 ncell, const u32 *__restrict__ cnt,
+								 const u32 *__restrict__ incl, WItem *__restrict__ items)
+{
+	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (i >= ncell)
+		return;
+	u32 cell = (i / (u32)rows) * (u32)nby + (u32)gy_lo + (i % (u32)rows);
+	u32 sp = span[cell], off = offset[cell], n = cnt[i];
+	u32 base = incl[i] - n;
+	for (u32 s = 0; s < n; s++) {
+		WItem w;
+		w.cell = cell;
+		w.begin = off + s * SEG;
+		u32 left = sp - s * SEG;
+		w.count = sp ? (left < SEG ? left : SEG) : 0u;
+		w.multi = n > 1;
+		items[base + s] = w;
+	}
+}
+
+// shadow: one entry per traced chunk; the chunk's light cell is the sorted key
+// of its first ray (light_kernel.cu:111); the sentinel cell has no triangles
+__global__ __launch_bounds__(WL_THREADS) void k_wl_count_shadow(const u32 *__restrict__ span, u32 C,
+								 const u32 *__restrict__ map, u32 n,
+								 const u32 *__restrict__ prefix, u32 nchunk_traced,
+								 u32 *__restrict__ cnt)
+{
+	u32 k = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (k >= nchunk_traced)
+		return;
+	u32 cell = map[n + prefix[k]];
+	u32 sp = cell < C ? span[cell] : 0u;
+	cnt[k] = (sp + SEG - 1) / SEG; // 0 triangles: nothing can shadow these rays
+}
+
+__global__ __launch_bounds__(WL_THREADS) void k_wl_fill_shadow(const u32 *__restrict__ span,
+								const u32 *__restrict__ offset, u32 C,
+								const u32 *__restrict__ map, u32 n,
+								const u32 *__restrict__ prefix, u32 nchunk_traced,
+								const u32 *__restrict__ cnt, const u32 *__restrict__ incl,
+								WItem *__restrict__ items)
+{
+	u32 k = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (k >= nchunk_traced)
+		return;
+	u32 cell = map[n + prefix[k]];
+	u32 sp = cell < C ? span[cell] : 0u;
+	u32 off = cell < C ? offset[cell] : 0u;
+	u32 m = cnt[k], base = incl[k] - m;
+	for (u32 s = 0; s < m; s++) {
+		WItem w;
+		w.cell = k;
+		w.begin = off + s * SEG;
+		u32 left = sp - s * SEG;
+		w.count = left < SEG ? left : SEG;
+		w.multi = 0;
+		items[base + s] = w;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// primary rays: rckernel_alpha, trace_kernel.cu:84-270 (NUM_SLABS = 1)
+// ---------------------------------------------------------------------------
+struct PrimaryOut {
+	float *normal;
+	float *t_value;
+	float *ray_dir;
+	int *shadowed;
+	int *intersect_id;
+};
+
+// trace_kernel.cu:56-82 isWithin + :230-267 epilogue for one pixel.
+// `ref` = index into value_list of the nearest accepted triangle, ~0u = none.
+__device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const PrimaryOut &o, int pixelID,
+					       const float *dir, float oldt, u32 ref,
+					       const u32 *__restrict__ value_list, const float *__restrict__ verts,
+					       const int *__restrict__ tris)
+{
+	bool ok = false;
+	if (ref != 0xFFFFFFFFu) {
+		float px = cam.cc[0] + oldt * dir[0];
+		float py = cam.cc[1] + oldt * dir[1];
+		float pz = cam.cc[2] + oldt * dir[2];
+		const float *m = cam.cc;
+		float hz = D_MULMV_ROW(m, 48, 2, px, py, pz);
+		float hw = D_MULMV_ROW(m, 48, 3, px, py, pz);
+		hz /= hw;
+		ok = ugrt_floor2i(hz * 1.0f) == 0;
+	}
+	if (ok) {
+		u32 face = value_list[ref];
+		float tri[9];
+		d_stage_triangle(verts, tris, face, 0.0f, 0.0f, 0.0f, tri);
+		float *e1 = &tri[3], *e2 = &tri[6], nrm[3];
+		D_NORMALIZE(e1);
+		D_NORMALIZE(e2);
+		D_CROSS(nrm, e1, e2);
+		D_NORMALIZE(nrm);
+		nrm[0] = nrm[0] < 0 ? nrm[0] * -1 : nrm[0];
+		nrm[1] = nrm[1] < 0 ? nrm[1] * -1 : nrm[1];
+		nrm[2] = nrm[2] < 0 ? nrm[2] * -1 : nrm[2];
+		o.t_value[pixelID] = oldt;
+		o.intersect_id[pixelID] = (int)face;
+		o.normal[pixelID * 3 + 0] = nrm[0];
+		o.normal[pixelID * 3 + 1] = nrm[1];
+		o.normal[pixelID * 3 + 2] = nrm[2];
+	} else {
+		o.t_value[pixelID] = -1.0f;
+		o.intersect_id[pixelID] = -2;
+		o.normal[pixelID * 3 + 0] = -1.0f;
+		o.normal[pixelID * 3 + 1] = -1.0f;
+		o.normal[pixelID * 3 + 2] = -1.0f;
+	}
+	o.shadowed[pixelID] = 0;
+	o.ray_dir[pixelID * 3 + 0] = dir[0];
+	o.ray_dir[pixelID * 3 + 1] = dir[1];
+	o.ray_dir[pixelID * 3 + 2] = dir[2];
+}
+
+__global__ __launch_bounds__(64) void k_trace_primary(CamBlock cam, const float *__restrict__ tex,
+						       const WItem *__restrict__ items,
+						       const u32 *__restrict__ nitems_p,
+						       const u32 *__restrict__ value_list,
+						       const float *__restrict__ verts, const int *__restrict__ tris,
+						       PrimaryOut out, u64 *__restrict__ best, int p0)
+{
+	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
+	const int lane = threadIdx.x;
+	const u32 nitems = *nitems_p;
+	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
+	for (u32 it = blockIdx.x; it < nitems; it += gridDim.x) {
+		const WItem w = items[it];
+		const int bx = (int)(w.cell / (u32)cam.nby), by = (int)(w.cell % (u32)cam.nby);
+		const int col = bx * 8 + (lane & 7), row = by * 8 + (lane >> 3);
+		const int pixelID = row * cam.W + col;
+		float dir[3];
+		d_ray_dir(cam, tex, col, row, dir);
+		float oldt = 99999999.9f;
+		u32 ref = 0xFFFFFFFFu;
+		for (u32 b = 0; b < w.count; b += 64) {
+			const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
+			__syncthreads(); // the previous batch has been consumed
+			if ((u32)lane < cnt) {
+				float t9[9];
+				d_stage_triangle(verts, tris, value_list[w.begin + b + lane], ex, ey, ez, t9);
+				float4 *dst = reinterpret_cast<float4 *>(&lds[lane * TRI_STRIDE]);
+				dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
+				dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
+				dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
+			}
+			__syncthreads();
+			for (u32 k = 0; k < cnt; k++) {
+				const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
+				const float4 a = src[0], c = src[1], e = src[2];
+				const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
+				const float v = d_intersect_tri_uv(tv, e1, e2, dir, oldt);
+				if (v != 0.0f) {
+					oldt = v;
+					ref = w.begin + b + k;
+				}
+			}
+		}
+		if (!w.multi) {
+			d_finish_pixel(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris);
+		} else if (ref != 0xFFFFFFFFu) {
+			atomicMin(reinterpret_cast<unsigned long long *>(&best[pixelID - p0]),
+				  ((unsigned long long)__float_as_uint(oldt) << 32) | (unsigned long long)ref);
+		}
+	}
+}
+
+// pixels of split cells: take the merged (t, ref), finish, re-arm the slot
+__global__ __launch_bounds__(256) void k_resolve_primary(CamBlock cam, const float *__restrict__ tex,
+							  const u32 *__restrict__ span,
+							  const u32 *__restrict__ value_list,
+							  const float *__restrict__ verts, const int *__restrict__ tris,
+							  PrimaryOut out, u64 *__restrict__ best, int p0, int npix)
+{
+	int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= npix)
+		return;
+	int pixelID = p0 + i;
+	int col = pixelID % cam.W, row = pixelID / cam.W;
+	u32 cell = (u32)(col >> 3) * (u32)cam.nby + (u32)(row >> 3);
+	if (span[cell] <= SEG)
+		return;
+	u64 b = best[i];
+	best[i] = ~0ull;
+	float dir[3];
+	d_ray_dir(cam, tex, col, row, dir);
+	u32 ref = (u32)(b & 0xFFFFFFFFull);
+	float oldt = (b == ~0ull) ? 99999999.9f : __uint_as_float((u32)(b >> 32));
+	if (b == ~0ull)
+		ref = 0xFFFFFFFFu;
+	d_finish_pixel(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris);
+}
+
+static int launch_blocks_for(u32 upper)
+{
+	// 256 CUs x 8 single-wave workgroups per SIMD-quad; waves are persistent
+	u32 g = 256u * 32u;
+	if (upper < g)
+		g = upper ? upper : 1u;
+	return (int)g;
+}
+
+// total refs behind a span/offset pair: known for the context's own grids,
+// read back (one 8-byte copy) for arrays that came from elsewhere
+static int refs_of(ugrt_ctx *ctx, const u32 *d_span, const u32 *d_offset, u32 C, u32 *R)
+{
+	for (int g = 0; g < 3; g++)
+		if (ctx->grid[g].valid && d_span == (const u32 *)ctx->grid[g].span.p &&
+		    d_offset == (const u32 *)ctx->grid[g].offset.p) {
+			*R = ctx->grid[g].R;
+			return UGRT_OK;
+		}
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 8, d_span + (C - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 9, d_offset + (C - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	*R = ctx->h_pinned[8] + ctx->h_pinned[9];
+	return UGRT_OK;
+}
+
+// FrustumTracer::trace, frustum_tracer.h:35-58
+extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
+				  const unsigned *d_offset, float *d_normal, float *d_t_value, float *d_ray_dir,
+				  int *d_shadowed, int *d_intersect_id, const float *d_vertlist, const int *d_trilist)
+{
+	if (!ctx || !d_value_list || !d_span || !d_offset || !d_normal || !d_t_value || !d_ray_dir || !d_shadowed ||
+	    !d_intersect_id || !d_vertlist || !d_trilist)
+		return ugrt_fail(UGRT_EINVAL, "trace_primary: null argument");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	const int rows = ctx->cfg.row_end - ctx->cfg.row_begin;
+	const u32 ncell = (u32)ctx->nbx * (u32)rows;
+	const u32 C = (u32)ctx->nbx * (u32)ctx->nby;
+	u32 R = 0;
+	int rc = refs_of(ctx, d_span, d_offset, C, &R);
+	if (rc)
+		return rc;
+	const size_t cap = (size_t)ncell + R / SEG + 1;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->wcount, (size_t)ncell * 4)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)ncell * 4)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, cap * sizeof(WItem))))
+		return rc;
+	u32 *cnt = (u32 *)ctx->wcount.p, *incl = (u32 *)ctx->wscan.p;
+	WItem *items = (WItem *)ctx->witems.p;
+	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
+	hipLaunchKernelGGL(k_wl_count_primary, dim3((ncell + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   d_span, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt);
+	UGRT_HIP(hipGetLastError());
+	if ((rc = ugrt_prim_inclusive_scan(ctx, cnt, incl, ncell)))
+		return rc;
+	hipLaunchKernelGGL(k_wl_fill_primary, dim3((ncell + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   d_span, d_offset, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt, incl, items);
+	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+	UGRT_HIP(hipGetLastError());
+	PrimaryOut out = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
+	ugrt_prof_begin(ctx, UGRT_ST_TRACE_PRIMARY);
+	hipLaunchKernelGGL(k_trace_primary, dim3(launch_blocks_for((u32)cap)), dim3(64), 0, st, ctx->cam,
+			   (const float *)ugrt_ctx_tex(ctx), (const WItem *)items, (const u32 *)(incl + (ncell - 1)),
+			   d_value_list, d_vertlist, d_trilist, out, (u64 *)ctx->best.p, ctx->p0);
+	UGRT_HIP(hipGetLastError());
+	hipLaunchKernelGGL(k_resolve_primary, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
+			   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist, out,
+			   (u64 *)ctx->best.p, ctx->p0, ctx->npix);
+	ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
+	UGRT_HIP(hipGetLastError());
+	ctx->stats[0] = cap; // upper bound of primary work items
+	return UGRT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// shadow rays: mod_light_rckernel, light_kernel.cu:52-270 (cam = LIGHT camera)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *__restrict__ items,
+						      const u32 *__restrict__ nitems_p,
+						      const u32 *__restrict__ curflist, const float *__restrict__ verts,
+						      const int *__restrict__ tris, const float *__restrict__ t_value_list,
+						      const float *__restrict__ ray_direction_list,
+						      int *__restrict__ is_shadowed, const u32 *__restrict__ d_map,
+						      const u32 *__restrict__ prefix, u32 nchunks, u32 n,
+						      const float *__restrict__ cmPt)
+{
+	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
+	const int lane = threadIdx.x;
+	const u32 nitems = *nitems_p;
+	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
+	const float cx = cmPt[0], cy = cmPt[1], cz = cmPt[2];
+	for (u32 it = blockIdx.x; it < nitems; it += gridDim.x) {
+		const WItem w = items[it];
+		const u32 start = prefix[w.cell];
+		const u32 end = (w.cell + 1 < nchunks) ? prefix[w.cell + 1] : n;
+		const bool have_ray = start + (u32)lane < end;
+		int pseudoPixelId = 0;
+		float rd[3] = { 0.0f, 0.0f, 1.0f }, distance_b = 0.0f;
+		if (have_ray) {
+			// light_kernel.cu:166-184
+			pseudoPixelId = (int)d_map[start + lane];
+			float tVal = t_value_list[pseudoPixelId];
+			float pI[3];
+			pI[0] = cx + tVal * ray_direction_list[pseudoPixelId * 3 + 0];
+			pI[1] = cy + tVal * ray_direction_list[pseudoPixelId * 3 + 1];
+			pI[2] = cz + tVal * ray_direction_list[pseudoPixelId * 3 + 2];
+			rd[0] = pI[0] - lx;
+			rd[1] = pI[1] - ly;
+			rd[2] = pI[2] - lz;
+			// isSmaller's distance_b (light_kernel.cu:6) depends on the ray only
+			distance_b = __builtin_sqrtf((pI[0] - lx) * (pI[0] - lx) + (pI[1] - ly) * (pI[1] - ly) +
+						     (pI[2] - lz) * (pI[2] - lz));
+			D_NORMALIZE(rd);
+		}
+		bool done = !have_ray; // rayDoneMap == 2
+		bool hit = false;
+		for (u32 b = 0; b < w.count; b += 64) {
+			const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
+			__syncthreads();
+			if ((u32)lane < cnt) {
+				float t9[9];
+				d_stage_triangle(verts, tris, curflist[w.begin + b + lane], lx, ly, lz, t9);
+				float4 *dst = reinterpret_cast<float4 *>(&lds[lane * TRI_STRIDE]);
+				dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
+				dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
+				dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
+			}
+			__syncthreads();
+			if (!done) {
+				for (u32 k = 0; k < cnt; k++) {
+					const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
+					const float4 a = src[0], c = src[1], e = src[2];
+					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y },
+						    e2[3] = { c.z, c.w, e.x };
+					const float value = d_intersect_tri(tv, e1, e2, rd, 999999.9f);
+					if (value != 0.0f) {
+						// light_kernel.cu:193-202 with isSmaller (:1-11)
+						float pt[3];
+						pt[0] = lx + value * rd[0];
+						pt[1] = ly + value * rd[1];
+						pt[2] = lz + value * rd[2];
+						float distance_a =
+							__builtin_sqrtf((pt[0] - lx) * (pt[0] - lx) + (pt[1] - ly) * (pt[1] - ly) +
+									(pt[2] - lz) * (pt[2] - lz));
+						if (distance_a + 1e-03f < distance_b) {
+							hit = true;
+							done = true;
+							break;
+						}
+					}
+				}
+			}
+			// the whole beam is decided: skip the remaining triangle batches
+			if (__ballot(!done) == 0ull)
+				break;
+		}
+		if (hit)
+			is_shadowed[pseudoPixelId] = 1;
+	}
+}
+
+// check_for_shadows, per_frame_funcs.h:139-159
+extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, const float *d_vertlist,
+				 const int *d_trilist, const unsigned *d_span, const unsigned *d_offset,
+				 const float *d_t_value, const float *d_ray_dir, int *d_is_shadowed,
+				 const unsigned *d_map, const unsigned *d_prefix_map, const float *d_cam_position,
+				 unsigned num_chunks)
+{
+	if (!ctx || !d_value_list || !d_vertlist || !d_trilist || !d_span || !d_offset || !d_t_value || !d_ray_dir ||
+	    !d_is_shadowed || !d_map || !d_prefix_map || !d_cam_position)
+		return ugrt_fail(UGRT_EINVAL, "trace_shadow: null argument");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	const u32 C = (u32)ctx->cfg.light_nbx * (u32)ctx->cfg.light_nby;
+	const u32 n = (u32)ctx->npix;
+	// which chunks get traced: the reference launches nbx*nby blocks, block b
+	// takes chunk b-1 and only blocks b < num_chunks work (light_kernel.cu:76-85)
+	u32 traced;
+	if (ctx->cfg.flags & UGRT_FLAG_SHADOW_ALL_CHUNKS) {
+		traced = num_chunks;
+	} else {
+		u32 launch = (u32)ctx->nbx * (u32)ctx->nby;
+		u32 lim = num_chunks < launch ? num_chunks : launch;
+		traced = lim ? lim - 1 : 0;
+	}
+	ctx->stats[2] = traced;
+	if (traced == 0)
+		return UGRT_OK;
+	u32 R = 0;
+	int rc = refs_of(ctx, d_span, d_offset, C, &R);
+	if (rc)
+		return rc;
+	// a cell's triangles are re-read by each of its chunks: items <= sum over chunks of ceil(span/SEG)
+	// bounded by traced + (refs of the busiest case); size from the exact count instead
+	if ((rc = ugrt_buf_reserve(ctx, ctx->wcount, (size_t)traced * 4)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)traced * 4)))
+		return rc;
+	u32 *cnt = (u32 *)ctx->wcount.p, *incl = (u32 *)ctx->wscan.p;
+	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
+	hipLaunchKernelGGL(k_wl_count_shadow, dim3((traced + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   d_span, C, d_map, n, d_prefix_map, traced, cnt);
+	UGRT_HIP(hipGetLastError());
+	if ((rc = ugrt_prim_inclusive_scan(ctx, cnt, incl, traced)))
+		return rc;
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, incl + (traced - 1), 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipStreamSynchronize(st));
+	const u32 nitems = ctx->h_pinned[10];
+	ctx->stats[1] = nitems;
+	if (nitems == 0) {
+		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+		return UGRT_OK;
+	}
+	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, (size_t)nitems * sizeof(WItem))))
+		return rc;
+	WItem *items = (WItem *)ctx->witems.p;
+	hipLaunchKernelGGL(k_wl_fill_shadow, dim3((traced + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   d_span, d_offset, C, d_map, n, d_prefix_map, traced, cnt, incl, items);
+	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+	UGRT_HIP(hipGetLastError());
+	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
+	hipLaunchKernelGGL(k_trace_shadow, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
+			   (const WItem *)items, (const u32 *)(incl + (traced - 1)), d_value_list, d_vertlist, d_trilist,
+			   d_t_value, d_ray_dir, d_is_shadowed, d_map, d_prefix_map, num_chunks, n, d_cam_position);
+	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
+	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// reflection bounce: 3D-DDA through the uniform grid (not in the reference;
+// DESIGN.md A13).  One lane per ray; Amanatides & Woo stepping.
+// ---------------------------------------------------------------------------
+struct DGrid {
+	float lo[3], cs[3], inv[3];
+	int dims[3];
+};
+
+__device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
+{
+	int c = ugrt_floor2i((p - g.lo[k]) * g.inv[k]);
+	return d_clampi(c, 0, g.dims[k] - 1);
+}
+
+__global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restrict__ value_list,
+						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
+						    const float *__restrict__ verts, const int *__restrict__ tris,
+						    const float *__restrict__ rays, const int *__restrict__ active,
+						    int p0, int npix, float *__restrict__ hit_t, int *__restrict__ hit_id)
+{
+	int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= npix)
+		return;
+	const int p = p0 + i;
+	float res_t = -1.0f;
+	int res_id = -2;
+	if (active[p]) {
+		float o[3], d[3], tmax[3], tdelta[3];
+		int c[3], step[3];
+		float tenter = 0.0f, texit = 3.0e38f;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			o[k] = rays[p * 6 + k];
+			d[k] = rays[p * 6 + 3 + k];
+		}
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			float lo = g.lo[k], hi = g.lo[k] + g.cs[k] * (float)g.dims[k];
+			if (d[k] != 0.0f) {
+				float inv = 1.0f / d[k];
+				float t0 = (lo - o[k]) * inv, t1 = (hi - o[k]) * inv;
+				if (t0 > t1) {
+					float s = t0;
+					t0 = t1;
+					t1 = s;
+				}
+				if (t0 > tenter)
+					tenter = t0;
+				if (t1 < texit)
+					texit = t1;
+			} else if (o[k] < lo || o[k] > hi) {
+				texit = -1.0f;
+			}
+		}
+		if (tenter <= texit) {
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				float pe = o[k] + tenter * d[k];
+				c[k] = d_dcell(g, k, pe);
+				if (d[k] > 0.0f) {
+					step[k] = 1;
+					tmax[k] = ((g.lo[k] + (float)(c[k] + 1) * g.cs[k]) - o[k]) / d[k];
+					tdelta[k] = g.cs[k] / d[k];
+				} else if (d[k] < 0.0f) {
+					step[k] = -1;
+					tmax[k] = ((g.lo[k] + (float)c[k] * g.cs[k]) - o[k]) / d[k];
+					tdelta[k] = -g.cs[k] / d[k];
+				} else {
+					step[k] = 0;
+					tmax[k] = 3.0e38f;
+					tdelta[k] = 3.0e38f;
+				}
+			}
+			float best_t = 3.0e38f;
+			int best_id = -2;
+			// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
+			for (int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3; guard > 0; guard--) {
+				u32 cell = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
+				u32 sp = span[cell], off = offset[cell];
+				int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
+				float tnext = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
+				for (u32 r = 0; r < sp; r++) {
+					u32 f = value_list[off + r];
+					float t9[9], t;
+					d_stage_triangle(verts, tris, f, o[0], o[1], o[2], t9);
+					if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
+						best_t = t;
+						best_id = (int)f;
+					}
+				}
+				if (best_id >= 0 && best_t <= tnext) {
+					res_t = best_t;
+					res_id = best_id;
+					break;
+				}
+				// step along ax (written out: no dynamically indexed registers)
+				bool outside;
+				if (ax == 0) {
+					c[0] += step[0];
+					outside = step[0] == 0 || c[0] < 0 || c[0] >= g.dims[0];
+					tmax[0] += tdelta[0];
+				} else if (ax == 1) {
+					c[1] += step[1];
+					outside = step[1] == 0 || c[1] < 0 || c[1] >= g.dims[1];
+					tmax[1] += tdelta[1];
+				} else {
+					c[2] += step[2];
+					outside = step[2] == 0 || c[2] < 0 || c[2] >= g.dims[2];
+					tmax[2] += tdelta[2];
+				}
+				if (outside)
+					break;
+			}
+		}
+	}
+	hit_t[p] = res_t;
+	hit_id[p] = res_id;
+}
+
+extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
+			      const unsigned *d_offset, const float *d_vertlist, const int *d_trilist,
+			      const float *d_rays, const int *d_active, float *d_hit_t, int *d_hit_id)
+{
+	if (!ctx || !d_value_list || !d_span || !d_offset || !d_vertlist || !d_trilist || !d_rays || !d_active ||
+	    !d_hit_t || !d_hit_id)
+		return ugrt_fail(UGRT_EINVAL, "trace_dda: null argument");
+	Grid &G = ctx->grid[UGRT_GRID_UNIFORM];
+	if (!G.valid)
+		return ugrt_fail(UGRT_EINVAL, "trace_dda: build the uniform grid first (it defines the cell geometry)");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	DGrid g;
+	for (int k = 0; k < 3; k++) {
+		g.lo[k] = G.ug[k];
+		g.cs[k] = G.ug[3 + k];
+		g.inv[k] = G.ug[6 + k];
+		g.dims[k] = G.dims[k];
+	}
+	ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
+	hipLaunchKernelGGL(k_trace_dda, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g, d_value_list,
+			   d_span, d_offset, d_vertlist, d_trilist, d_rays, d_active, ctx->p0, ctx->npix, d_hit_t,
+			   d_hit_id);
+	ugrt_prof_end(ctx, UGRT_ST_TRACE_DDA);
+	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}

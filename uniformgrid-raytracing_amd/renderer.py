@@ -1,0 +1,144 @@
+"""display() of the reference (main.cu:59-302) over the C-ABI.
+
+One :class:`Renderer` owns what the reference's ``DecisionData`` (decision_data.h:13-40),
+``Model`` device lists (scene.h:24-28) and the image buffer own, as torch tensors, and
+sequences one frame exactly in the reference's order:
+
+  updateLightPosition -> camera -> fillCoordinatesData -> build_frustum_grid ->
+  FrustumTracer::trace -> per light { light camera -> fillCoordinatesData ->
+  getEffectiveRayGridMapping -> build_secondary_frustum_grid -> processData ->
+  check_for_shadows } -> simpleShade | spotlight_shade -> add_shadows
+
+(getRayGridMapping + the host max loop, main.cu:172-187, only produce values that
+are overwritten with M_PI, so they are dropped: xM = yM = (float)M_PI.)
+With ``reflect=True`` the shading step becomes: secondary rays -> uniform grid
+build -> 3D-DDA -> shade_reflect (not in the reference).
+"""
+import numpy as np
+
+from . import GRID_PERSPECTIVE, GRID_SPHERICAL, GRID_UNIFORM
+from .host import Camera
+
+PI_F = float(np.float32(np.pi))
+
+
+class FrameSetup:
+    def __init__(self, camera, light_camera, shading_light, fovy=45.0):
+        self.camera, self.light_camera, self.shading_light, self.fovy = camera, light_camera, shading_light, fovy
+
+    @staticmethod
+    def from_scene(info, cam="ref"):
+        cams = info["cameras"]
+        return FrameSetup(cams[cam] if cam in cams else next(iter(cams.values())), info["light_camera"],
+                          info["shading_light"])
+
+
+def make_camera(params, fovy, aspect):
+    c = Camera(fovy, aspect)
+    c.setCameraCenter(*params["eye"])
+    c.setCameraLookAt(*params["look"])
+    c.setCameraUp(*params["up"])
+    c.setNearFar(params["near"], params["far"])
+    return c.adjustCameraAndPosition()
+
+
+class Renderer:
+    def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3):
+        t = ctx.torch
+        self.ctx = ctx
+        self.F = int(len(faces))
+        self.num_materials = int(len(mat_list) // 6 if np.ndim(mat_list) == 1 else len(mat_list))
+        self.d_verts = ctx.upload(np.asarray(verts, np.float32).reshape(-1))
+        self.d_faces = ctx.upload(np.asarray(faces, np.int32).reshape(-1))
+        self.d_matidx = ctx.upload(np.asarray(matidx, np.int32).reshape(-1))
+        self.d_matlist = ctx.upload(np.asarray(mat_list, np.float32).reshape(-1))
+        refl = np.zeros(self.num_materials, np.float32) if reflect is None else np.asarray(reflect, np.float32)
+        self.d_reflect = ctx.upload(refl)
+        v = np.asarray(verts, np.float32).reshape(-1, 3)
+        self.bbmin, self.bbmax = v.min(0), v.max(0)
+        N = ctx.width * ctx.height
+        self.N = N
+        # DecisionData, decision_data.h:64-78
+        self.normal = ctx.empty(3 * N, t.float32)
+        self.t = ctx.empty(N, t.float32)
+        self.dir = ctx.empty(3 * N, t.float32)
+        self.is_shadowed = ctx.empty(N, t.int32)
+        self.intersect_id = ctx.empty(N, t.int32)
+        self.d_map = ctx.empty(2 * ctx.npix, t.int32)
+        self.prefix = ctx.empty(ctx.prefix_capacity(), t.int32)
+        self.image = t.zeros(3 * N, dtype=t.uint8, device=ctx.device)
+        self.cam_pos = ctx.empty(3, t.float32)
+        self.rays = self.active = self.hit_t = self.hit_id = None
+        self.reflect_eps = float(reflect_eps)
+        self.num_chunks = 0
+        self.orig = None
+        self.aspect = float(np.float32(ctx.width) / np.float32(ctx.height))
+
+    # Model::init_orig_list, scene.h:336
+    def init_orig_list(self, size, offset):
+        self.orig = self.d_verts[3 * offset:3 * (offset + size)].clone()
+        self.orig_size, self.orig_offset = size, offset
+
+    # Model::rotate_bunny, scene.h:122
+    def rotate_bunny(self, rot):
+        self.ctx.animate(self.d_verts, self.orig, self.orig_size, self.orig_offset, rot)
+
+    def _ensure_reflect_buffers(self):
+        if self.rays is None:
+            t = self.ctx.torch
+            self.rays = self.ctx.empty(6 * self.N, t.float32)
+            self.active = self.ctx.empty(self.N, t.int32)
+            self.hit_t = self.ctx.empty(self.N, t.float32)
+            self.hit_id = self.ctx.empty(self.N, t.int32)
+
+    def display(self, setup, frame_cnt=1, shadows=True, reflect=False, shade=True):
+        ctx = self.ctx
+        t = ctx.torch
+        # updateLightPosition, per_frame_funcs.h:6
+        ctx.set_light_position(setup.shading_light)
+        cam = make_camera(setup.camera, setup.fovy, self.aspect)
+        # main.cu:128 d_cam_position <- worldori ; fillCoordinatesData
+        self.cam_pos.copy_(t.from_numpy(cam.worldori[:3].copy()), non_blocking=False)
+        ctx.upload_camera(cam.camcoords)
+        # build_frustum_grid
+        ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
+        value, _, span, offset, _ = ctx.grid_arrays(GRID_PERSPECTIVE)
+        # FrustumTracer::trace
+        ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed, self.intersect_id,
+                          self.d_verts, self.d_faces)
+        if shadows:
+            lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
+            ctx.upload_camera(lcam.camcoords)
+            ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
+            ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
+            lvalue, _, lspan, loffset, _ = ctx.grid_arrays(GRID_SPHERICAL)
+            self.num_chunks = ctx.sort_rays(self.d_map, self.prefix)
+            ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
+                             self.d_map, self.prefix, self.cam_pos, self.num_chunks)
+        if not shade:
+            return
+        if reflect:
+            self._ensure_reflect_buffers()
+            ctx.reflect_rays(self.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
+                             self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays,
+                             self.active)
+            ctx.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
+            uvalue, _, uspan, uoffset, _ = ctx.grid_arrays(GRID_UNIFORM)
+            ctx.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active, self.hit_t,
+                          self.hit_id)
+            ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                              self.d_matidx, self.d_matlist, self.d_reflect, self.num_materials, self.d_verts,
+                              self.d_faces, self.rays, self.active, self.hit_t, self.hit_id)
+        elif frame_cnt < 2:
+            ctx.shade_simple(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                             self.d_matidx, self.d_matlist, self.num_materials)
+        else:
+            ctx.shade_spotlight(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                                self.d_matidx, self.d_matlist, self.num_materials)
+        if shadows:
+            ctx.shade_add_shadows(self.image, self.is_shadowed)
+
+    def band_image(self):
+        """uint8 view [rows*8, W, 3] of this context's band."""
+        ctx = self.ctx
+        return self.image[3 * ctx.p0:3 * (ctx.p0 + ctx.npix)].view(-1, ctx.width, 3)

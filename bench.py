@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render hot path on MI355X.
+
+Metric (BASELINE.json): Mrays/s (primary + shadow + 1 reflection bounce).
+One "step" = one frame of display() (main.cu:59-302) over the C-ABI:
+perspective grid build -> primary rays -> light-space mapping -> spherical grid build ->
+ray sort + chunking -> shadow rays -> secondary rays -> uniform grid build -> 3D-DDA ->
+shading -> (N > 1) RCCL gather of the RGB bands to rank 0.  All three grids are REBUILT every
+frame (as the reference does), scene and buffers are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+N = 1: BASELINE configs[2] (1M-triangle "crashing" stand-in, 1920x1080).  N > 1: one process
+per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE), the image is cut into bands of tile rows
+and grows with N at fixed 16:9 aspect (weak scaling; N = 4 is configs[3]'s 3840x2160).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def load_scene(ugrt, workload, scale, rank):
+    """Generate the procedural scene, write it as .obj/.mtl/.mat and load it through the product's loader."""
+    t0 = time.time()
+    d = tempfile.mkdtemp(prefix="ugrt_bench_r%d_" % rank)
+    gen = {"crash": ugrt.scenes.crash, "hall": ugrt.scenes.hall}[workload]
+    info = gen(d, scale=scale)
+    m = ugrt.Model()
+    m.some_material(info["mat"])
+    m.load_model(info["obj"])
+    s = dict(info)
+    s["verts"] = m.h_vertexlist.reshape(-1, 3)
+    s["faces"] = m.h_facelist.reshape(-1, 3)
+    s["matidx"] = m.h_materiallist_index
+    s["mat_list"] = m.h_materiallist.reshape(-1, 6)
+    s["reflect"] = m.h_reflectlist
+    for f in (info["obj"], info["mtl"], info["mat"]):
+        os.unlink(f)
+    os.rmdir(d)
+    log("[bench] rank %d: scene %s: %d triangles, generated + written + parsed in %.1f s"
+        % (rank, info["name"], s["num_faces"], time.time() - t0))
+    return s
+
+
+def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
+    """SURVEY.md section 8(d) formulas, per launch of each tracer, for this rank's band."""
+    out = {}
+    rows = ctx.rows[1] - ctx.rows[0]
+    C_band = ctx.nbx * rows
+    gi = ctx.grid_info(ugrt.GRID_PERSPECTIVE)
+    out["trace_primary"] = 8 * C_band + 52 * gi.total_refs + 36 * ctx.npix
+    # shadow: 24 N + sum over traced chunks (8 + 52 span(cell(chunk)))
+    _, _, lspan, _, lgi = ctx.grid_arrays(ugrt.GRID_SPHERICAL)
+    n, nch = ctx.npix, r.num_chunks
+    heads = r.prefix[:nch].long()
+    cells = r.d_map[n:2 * n][heads].long()
+    C_l = lgi.num_cells
+    sp = torch.where(cells < C_l, lspan[cells.clamp(max=C_l - 1)].long(), torch.zeros_like(cells))
+    out["trace_shadow"] = 24 * n + 8 * nch + 52 * int(sp.sum().item())
+    tests, cells_visited, active = dda_counts
+    out["trace_dda"] = 48 * active + 8 * cells_visited + 52 * tests
+    out["_R_perspective"], out["_R_spherical"] = gi.total_refs, lgi.total_refs
+    out["_R_uniform"] = ctx.grid_info(ugrt.GRID_UNIFORM).total_refs
+    out["_shadow_span_sum"], out["_chunks"] = int(sp.sum().item()), nch
+    return out
+
+
+def cpu_baseline(ugrt, s, setup, W, H, lg, udims, seconds):
+    """The oracle (CPU restatement, kind "port") on the host cores: grid builds timed in full,
+    tracing on a band of tile rows, scaled to the frame."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # the checker, used here only as the timed CPU baseline
+
+    cores = O.set_threads(os.cpu_count() or 1)
+    nby = H // 8
+    fixed = ("build_spherical", "build_uniform")
+
+    def run(rows):
+        t0 = time.perf_counter()
+        fr = O.frame(s, setup, W, H, rows=rows, light_grid=lg, all_chunks=True, reflect=True, uniform_dims=udims)
+        wall = time.perf_counter() - t0
+        rays = 2 * fr["n"] + int(fr["active"].sum())
+        tf = sum(fr["times"][k] for k in fixed)
+        return wall, tf, rays
+
+    mid = nby // 2
+    w1, f1, _ = run((mid, mid + 2))
+    per_row = max((w1 - f1) / 2.0, 1e-4)
+    nrows = int(max(2, min(nby, (seconds - f1) / per_row)))
+    lo = max(0, mid - nrows // 2)
+    rows = (lo, min(nby, lo + nrows))
+    wall, tf, rays = run(rows)
+    scale = nby / float(rows[1] - rows[0])
+    t_full = tf + (wall - tf) * scale
+    value = rays * scale / t_full / 1e6
+    return dict(value=round(value, 4), unit="Mrays/s", cores=cores, kind="port",
+                sample="oracle frame on tile rows [%d,%d) of %d (%.1f s wall; spherical+uniform grid builds "
+                       "%.2f s counted once, the rest scaled x%.2f to the frame)"
+                       % (rows[0], rows[1], nby, wall, tf, scale))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="crash", choices=["crash", "hall"])
+    ap.add_argument("--scale", type=float, default=1.0, help="triangle-count scale of the scene (1.0 = BASELINE)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--stages-json", default="", help="also write the per-stage table to this file")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import ugrt
+    from ugrt import parallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: libugrt has no CPU fallback"
+    torch.cuda.set_device(local)
+
+    if args.width and args.height:
+        W, H = args.width, args.height
+    elif args.workload == "hall":
+        W, H = parallel.weak_scaling_resolution(world, base=(1024, 1024))
+    else:
+        W, H = parallel.weak_scaling_resolution(world)
+    nby = H // 8
+    rows = parallel.band_rows(rank, world, nby)
+    lg, udims = (128, 128), (128, 128, 64)
+
+    s = load_scene(ugrt, args.workload, args.scale, rank)
+    setup = ugrt.FrameSetup.from_scene(s)
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS
+    ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
+    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world)
+
+    def step():
+        r.display(setup, frame_cnt=1, shadows=True, reflect=True)
+        gather.gather(r.image)
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+
+    # rays per frame of this rank: primary + shadow (one per pixel, misses included: misc_kernel.cu:255)
+    # + secondary rays actually shot
+    active = int(r.active[ctx.p0:ctx.p0 + ctx.npix].sum().item())
+    rays_rank = 2 * ctx.npix + active
+
+    # work counters for the DDA's algorithmic bytes: a counting context, outside the timed region
+    cctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags | ugrt.FLAG_COUNT_WORK,
+                        uniform_dims=udims)
+    cr = ugrt.Renderer(cctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    cr.display(setup, frame_cnt=1, shadows=True, reflect=True)
+    cctx.synchronize()
+    st = cctx.stats()
+    dda_counts = (st[3], st[4], st[5])
+    assert st[5] == active, (st[5], active)
+    del cr, cctx
+    abytes = algorithmic_bytes(torch, ugrt, ctx, r, dda_counts)
+
+    # ---- timed region: exactly K steps between barrier + synchronize pairs -------------------
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_get()
+    ctx.prof_enable(False)
+
+    tot = torch.tensor([elapsed, float(rays_rank)], dtype=torch.float64, device=ctx.device)
+    if dist is not None:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0].item())
+        rays_total = float(tot[1].item())
+    else:
+        rays_total = float(rays_rank)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    stages = {k: dict(ms_per_launch=v[0] / v[1], launches_per_step=v[1] / float(args.steps),
+                      ms_per_step=v[0] / args.steps) for k, v in prof.items() if v[1]}
+    gpu_ms = sum(v["ms_per_step"] for v in stages.values())
+    dom = max(("trace_primary", "trace_shadow", "trace_dda"), key=lambda k: stages.get(k, {}).get("ms_per_step", 0))
+    dom_ms = stages[dom]["ms_per_launch"]
+    achieved = abytes[dom] / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath))
+            key = "%s:%s:%dx%d:scale%g" % (args.workload, dom, W, H, args.scale)
+            traffic = rec.get(key)
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel={"trace_primary": "k_trace_primary", "trace_shadow": "k_trace_shadow",
+                                         "trace_dda": "k_trace_dda"}[dom],
+                    achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
+                    traffic=traffic, algorithmic_bytes_per_launch=int(abytes[dom]), ms_per_launch=round(dom_ms, 4))
+
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:
+        try:
+            cpu = cpu_baseline(ugrt, s, setup, W, H, lg, udims, args.cpu_seconds)
+        except Exception as e:  # the baseline is a report, never a reason to lose the measurement
+            cpu = dict(value=None, unit="Mrays/s", cores=0, kind="port", sample="failed: %r" % (e,))
+
+    value = rays_total / elapsed * args.steps / 1e6
+    line = {
+        "metric": "Mrays/s (primary+shadow+1-bounce)",
+        "value": round(value, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE configs[2] stand-in: procedural '%s' scene, %d triangles, %dx%d, primary + "
+                         "shadow (1 light, all chunks traced) + 1 reflection bounce; perspective, spherical and "
+                         "uniform grids rebuilt every frame" % (s["name"], s["num_faces"], W, H)),
+            "rays_per_frame": int(rays_total),
+            "tile": 8, "light_grid": list(lg), "uniform_grid": list(udims),
+            "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
+        "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
+        "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},
+    }
+    if args.stages_json:
+        with open(args.stages_json, "w") as fp:
+            json.dump(dict(stages=stages, abytes=abytes, line=line), fp, indent=1)
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

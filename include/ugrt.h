@@ -48,7 +48,10 @@ enum {
 	/* trace every shadow chunk instead of reproducing the reference's launch
 	 * (block b handles chunk b-1, at most nbx*nby blocks: light_kernel.cu:76-85,
 	 * per_frame_funcs.h:144) */
-	UGRT_FLAG_SHADOW_ALL_CHUNKS = 1u
+	UGRT_FLAG_SHADOW_ALL_CHUNKS = 1u,
+	/* tracers also count their work (DDA: candidates tested, cells visited, active rays) for
+	 * ugrt_stats_get; a counting context is for measurement set-up, never for timing */
+	UGRT_FLAG_COUNT_WORK = 2u
 };
 
 /* which grid of the context */
@@ -235,8 +238,9 @@ int ugrt_prof_reset(ugrt_ctx *ctx);
 /* total milliseconds and number of timed launches of a stage since the reset
  * (synchronises the stream) */
 int ugrt_prof_get(ugrt_ctx *ctx, int stage, double *ms_total, int *launches);
-/* counters of the last tracer launches: [0] primary work items, [1] shadow
- * work items, [2] shadow chunks traced */
+/* counters of the last tracer launches: [0] primary work-item capacity, [1] shadow work
+ * items, [2] shadow chunks traced; with UGRT_FLAG_COUNT_WORK also [3] DDA candidates tested,
+ * [4] DDA cells visited, [5] DDA active rays */
 int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8]);
 
 #ifdef __cplusplus

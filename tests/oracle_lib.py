@@ -257,7 +257,22 @@ def shade_reflect(cc, light_pos, img, normal, t, dirs, ids, cam_pos, mat_idx, ma
 
 def frame(scene, setup, W, H, rows=None, light_grid=(128, 128), all_chunks=False, shadows=True, reflect=False,
           uniform_dims=(64, 64, 32), frame_cnt=1, reflect_eps=1e-3, verts=None):
-    """display(), main.cu:59-302, on the CPU.  Returns every intermediate array."""
+    """display(), main.cu:59-302, on the CPU.  Returns every intermediate array and, in
+    r["times"], the seconds spent per stage (used by bench.py's cpu_baseline leg)."""
+    import time as _time
+
+    times = {}
+
+    class _T:
+        def __init__(self, name):
+            self.name = name
+
+        def __enter__(self):
+            self.t0 = _time.perf_counter()
+
+        def __exit__(self, *a):
+            times[self.name] = times.get(self.name, 0.0) + _time.perf_counter() - self.t0
+
     verts = _f32(scene["verts"] if verts is None else verts).reshape(-1)
     faces = _i32(scene["faces"]).reshape(-1)
     nbx, nby = W // 8, H // 8
@@ -265,9 +280,11 @@ def frame(scene, setup, W, H, rows=None, light_grid=(128, 128), all_chunks=False
     p0, n, N = lo * 8 * W, (hi - lo) * 8 * W, W * H
     aspect = float(np.float32(W) / np.float32(H))
     cam = cam_from(setup.camera, setup.fovy, aspect)
-    r = dict(cam=cam, p0=p0, n=n)
-    r["grid"] = grid_perspective(cam.cc, faces, verts, nbx, nby, (lo, hi))
-    r["primary"] = trace_primary(cam, W, H, r["grid"], verts, faces, (lo, hi))
+    r = dict(cam=cam, p0=p0, n=n, times=times)
+    with _T("build_perspective"):
+        r["grid"] = grid_perspective(cam.cc, faces, verts, nbx, nby, (lo, hi))
+    with _T("trace_primary"):
+        r["primary"] = trace_primary(cam, W, H, r["grid"], verts, faces, (lo, hi))
     pr = r["primary"]
     cam_pos = cam.worldori[:3].copy()
     is_shadowed = pr["shadowed"].copy()
@@ -277,29 +294,39 @@ def frame(scene, setup, W, H, rows=None, light_grid=(128, 128), all_chunks=False
         r["lcam"] = lcam
         cur_cc = lcam.cc
         lx, ly = light_grid
-        d_map = map_rays(lcam.cc, pr["t"], pr["dir"], cam_pos, lx, ly, p0, n)
+        with _T("map_rays"):
+            d_map = map_rays(lcam.cc, pr["t"], pr["dir"], cam_pos, lx, ly, p0, n)
         r["map_unsorted"] = d_map.copy()
-        r["lgrid"] = grid_spherical(lcam.cc, faces, verts, lx, ly)
-        prefix, nchunks = process_rays(d_map, n, lx * ly + 1, n // 64 + lx * ly + 2)
+        with _T("build_spherical"):
+            r["lgrid"] = grid_spherical(lcam.cc, faces, verts, lx, ly)
+        with _T("sort_rays"):
+            prefix, nchunks = process_rays(d_map, n, lx * ly + 1, n // 64 + lx * ly + 2)
         r["map"], r["prefix"], r["nchunks"] = d_map, prefix, nchunks
-        r["shadow_tests"] = trace_shadow(lcam.cc, r["lgrid"], lx * ly, verts, faces, pr["t"], pr["dir"], is_shadowed,
-                                         d_map, prefix, cam_pos, nchunks, nbx * nby, n, strict=not all_chunks)
+        with _T("trace_shadow"):
+            r["shadow_tests"] = trace_shadow(lcam.cc, r["lgrid"], lx * ly, verts, faces, pr["t"], pr["dir"],
+                                             is_shadowed, d_map, prefix, cam_pos, nchunks, nbx * nby, n,
+                                             strict=not all_chunks)
     r["is_shadowed"] = is_shadowed
     img = np.zeros(3 * N, np.uint8)
     ids = pr["id"].copy()
     if reflect:
         v3 = verts.reshape(-1, 3)
-        rays, active = reflect_rays(cam_pos, pr["t"], pr["dir"], pr["id"], scene["matidx"], scene["reflect"], verts,
-                                    faces, reflect_eps, p0, n, N)
-        r["ugrid"] = grid_uniform(faces, verts, v3.min(0), v3.max(0), uniform_dims)
-        hit_t, hit_id, cnt = trace_dda(r["ugrid"], verts, faces, rays, active, p0, n, N)
+        with _T("reflect_gen"):
+            rays, active = reflect_rays(cam_pos, pr["t"], pr["dir"], pr["id"], scene["matidx"], scene["reflect"],
+                                        verts, faces, reflect_eps, p0, n, N)
+        with _T("build_uniform"):
+            r["ugrid"] = grid_uniform(faces, verts, v3.min(0), v3.max(0), uniform_dims)
+        with _T("trace_dda"):
+            hit_t, hit_id, cnt = trace_dda(r["ugrid"], verts, faces, rays, active, p0, n, N)
         r.update(rays=rays, active=active, hit_t=hit_t, hit_id=hit_id, dda_counters=cnt)
-        shade_reflect(cur_cc, setup.shading_light, img, pr["normal"], pr["t"], pr["dir"], ids, cam_pos,
-                      scene["matidx"], scene["mat_list"], scene["reflect"], verts, faces, rays, active, hit_t, hit_id,
-                      p0, n)
+        with _T("shade"):
+            shade_reflect(cur_cc, setup.shading_light, img, pr["normal"], pr["t"], pr["dir"], ids, cam_pos,
+                          scene["matidx"], scene["mat_list"], scene["reflect"], verts, faces, rays, active, hit_t,
+                          hit_id, p0, n)
     else:
-        shade(cur_cc, setup.shading_light, img, pr["normal"], pr["t"], pr["dir"], ids, cam_pos, scene["matidx"],
-              scene["mat_list"], p0, n, spot=frame_cnt >= 2)
+        with _T("shade"):
+            shade(cur_cc, setup.shading_light, img, pr["normal"], pr["t"], pr["dir"], ids, cam_pos, scene["matidx"],
+                  scene["mat_list"], p0, n, spot=frame_cnt >= 2)
     r["image_unshadowed"] = img.copy()
     if shadows:
         add_shadows(img, is_shadowed, p0, n)

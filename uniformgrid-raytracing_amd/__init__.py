@@ -31,10 +31,19 @@ if not os.path.exists(LIB_PATH):
         "(or __graft_entry__.build()); there is no Python/CPU fallback" % (LIB_PATH, _HERE)
     )
 
+# PyTorch-ROCm bundles its own HIP runtime with the same SONAME as /opt/rocm's (libamdhip64.so.7).
+# Device pointers are only valid inside ONE runtime, so torch's copy has to be the one in the
+# process: load it before libugrt.so resolves its own dependency.
+try:
+    import torch  # noqa: F401
+except ImportError:  # host-only use (loader, camera, PPM) works without torch
+    torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 UGRT_OK, UGRT_EINVAL, UGRT_ENODEV, UGRT_EHIP, UGRT_EIO, UGRT_ENOMEM = range(6)
 FLAG_SHADOW_ALL_CHUNKS = 1
+FLAG_COUNT_WORK = 2
 GRID_PERSPECTIVE, GRID_SPHERICAL, GRID_UNIFORM = 0, 1, 2
 STAGES = [
     "build_count", "build_scan", "build_fill", "build_sort", "build_bounds", "trace_primary", "map_rays",

@@ -308,11 +308,13 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	hipLaunchKernelGGL(k_trace_primary, dim3(launch_blocks_for((u32)cap)), dim3(64), 0, st, ctx->cam,
 			   (const float *)ugrt_ctx_tex(ctx), (const WItem *)items, (const u32 *)(incl + (ncell - 1)),
 			   d_value_list, d_vertlist, d_trilist, out, (u64 *)ctx->best.p, ctx->p0);
+	ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
 	UGRT_HIP(hipGetLastError());
+	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
 	hipLaunchKernelGGL(k_resolve_primary, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
 			   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist, out,
 			   (u64 *)ctx->best.p, ctx->p0, ctx->npix);
-	ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
+	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	ctx->stats[0] = cap; // upper bound of primary work items
 	return UGRT_OK;
@@ -488,11 +490,13 @@ __device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
 	return d_clampi(c, 0, g.dims[k] - 1);
 }
 
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restrict__ value_list,
 						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
 						    const float *__restrict__ verts, const int *__restrict__ tris,
 						    const float *__restrict__ rays, const int *__restrict__ active,
-						    int p0, int npix, float *__restrict__ hit_t, int *__restrict__ hit_id)
+						    int p0, int npix, float *__restrict__ hit_t, int *__restrict__ hit_id,
+						    unsigned long long *__restrict__ counters)
 {
 	int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= npix)
@@ -500,6 +504,7 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 	const int p = p0 + i;
 	float res_t = -1.0f;
 	int res_id = -2;
+	u32 n_cells = 0, n_tests = 0;
 	if (active[p]) {
 		float o[3], d[3], tmax[3], tdelta[3];
 		int c[3], step[3];
@@ -555,6 +560,10 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 				u32 sp = span[cell], off = offset[cell];
 				int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
 				float tnext = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
+				if (COUNT) {
+					n_cells++;
+					n_tests += sp;
+				}
 				for (u32 r = 0; r < sp; r++) {
 					u32 f = value_list[off + r];
 					float t9[9], t;
@@ -591,6 +600,15 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 	}
 	hit_t[p] = res_t;
 	hit_id[p] = res_id;
+	if (COUNT) {
+		// work counters of the algorithmic-byte formula: candidates tested, cells visited, active rays
+		if (n_tests)
+			atomicAdd(&counters[0], (unsigned long long)n_tests);
+		if (n_cells)
+			atomicAdd(&counters[1], (unsigned long long)n_cells);
+		if (active[p])
+			atomicAdd(&counters[2], 1ull);
+	}
 }
 
 extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
@@ -611,10 +629,26 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		g.inv[k] = G.ug[6 + k];
 		g.dims[k] = G.dims[k];
 	}
+	if (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) {
+		// counting variant (never the timed one): same traversal + three atomics per ray
+		unsigned long long *dc = (unsigned long long *)(ctx->d_small + 8);
+		UGRT_HIP(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), ctx->stream));
+		hipLaunchKernelGGL(k_trace_dda<true>, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
+				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, d_rays, d_active, ctx->p0,
+				   ctx->npix, d_hit_t, d_hit_id, dc);
+		UGRT_HIP(hipGetLastError());
+		unsigned long long h[3];
+		UGRT_HIP(hipMemcpyAsync(h, dc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+		UGRT_HIP(hipStreamSynchronize(ctx->stream));
+		ctx->stats[3] = h[0];
+		ctx->stats[4] = h[1];
+		ctx->stats[5] = h[2];
+		return UGRT_OK;
+	}
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
-	hipLaunchKernelGGL(k_trace_dda, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g, d_value_list,
-			   d_span, d_offset, d_vertlist, d_trilist, d_rays, d_active, ctx->p0, ctx->npix, d_hit_t,
-			   d_hit_id);
+	hipLaunchKernelGGL(k_trace_dda<false>, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
+			   d_value_list, d_span, d_offset, d_vertlist, d_trilist, d_rays, d_active, ctx->p0, ctx->npix,
+			   d_hit_t, d_hit_id, (unsigned long long *)nullptr);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_DDA);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

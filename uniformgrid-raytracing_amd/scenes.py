@@ -120,8 +120,14 @@ def icosphere(level):
 
 
 def add_room(mesh, n=40):
-    """Room [0,28]x[0,26]x[0,9], walls tessellated n x n.  Materials: 0 floor, 1 walls, 2 ceiling."""
-    add_box(mesh, (0, 0, 0), (28, 26, 9), n, 1, faces="xXyY")
+    """Room [0,28]x[0,26]x[0,9], walls tessellated n x n.  Materials: 0 floor, 1 walls, 2 ceiling.
+
+    The wall x = 0 (behind the reference camera at (3,15,5)) is left out, like a stage set: the
+    reference's primary intersection takes |t| (trace_kernel.cu:35), so a wall
+    BEHIND the eye would win every pixel as a ghost hit and hide the scene.
+    """
+    add_box(mesh, (0, 0, 0), (28, 26, 9), n, 1, faces="XyY")
+    add_box(mesh, (0, 0, 0), (28, 26, 9), n, 0, faces="z")
     add_box(mesh, (0, 0, 0), (28, 26, 9), n, 0, faces="z")
     add_box(mesh, (0, 0, 0), (28, 26, 9), n, 2, faces="Z")
 
@@ -219,12 +225,12 @@ def cornell(outdir=None):
                    dict(cameras=cams, light_camera=light_cam, shading_light=(278.0, 500.0, 279.5)))
 
 
-def _hall_static(mesh, wall_n=40, col_seg=32, col_stack=24, vault=(64, 160)):
+def _hall_static(mesh, wall_n=40, col_seg=32, col_stack=26, vault=(64, 160)):
     add_room(mesh, wall_n)
     k = 0
-    for ix in range(8):
-        for iy in range(3):
-            cx, cy = 3.0 + ix * 3.2, 4.0 + iy * 9.0
+    for ix in range(12):
+        for iy in range(2):  # two rows, the centre aisle stays open for the reference camera
+            cx, cy = 3.0 + ix * 2.1, 5.0 + iy * 16.0
             add_cylinder(mesh, cx, cy, 0.0, 7.5, 0.45, col_seg, col_stack, 3, flutes=8)
             k += 1
     for s in range(3):
@@ -237,7 +243,7 @@ def hall(outdir=None, scale=1.0):
     """~80 000 triangles at scale 1 (scale < 1 shrinks the tessellation for CPU-sized tests)."""
     mesh = Mesh()
     s = max(0.05, scale) ** 0.5
-    _hall_static(mesh, wall_n=max(2, int(40 * s)), col_seg=max(6, int(32 * s)), col_stack=max(2, int(24 * s)),
+    _hall_static(mesh, wall_n=max(2, int(40 * s)), col_seg=max(6, int(32 * s)), col_stack=max(2, int(26 * s)),
                  vault=(max(4, int(64 * s)), max(8, int(160 * s))))
     return _finish(outdir, "hall%dk" % round(mesh.ntris() / 1000), mesh, MATERIALS_ROOM,
                    dict(cameras={"ref": REF_CAMERA}, light_camera=REF_LIGHT_CAMERA,

@@ -1,0 +1,103 @@
+"""Known answers that pin the oracle.  The reference ships no tests; SURVEY.md section 8(c) records three
+observations made by running the reference's kernels, which are the only reference outputs available:
+ (1) one triangle with ndc x,y in [-0.5,0.5] on the 128x128 grid -> sizeList = 65*65 = 4225 (DSKernel);
+ (2) centre tile, one triangle at z=-5 -> 64/64 hits, t=5, n=(0,0,1), dir=(0,0,-1), id 0 (rckernel_alpha);
+ (3) a backward ray returns t=+1 from intersectTriUV (abs) and t=-1 from intersectTri (signed).
+"""
+import numpy as np
+
+
+def ident_cam():
+    cc = np.zeros(64, np.float32)
+    for base in (16, 32, 48):
+        cc[base + 0] = cc[base + 5] = cc[base + 10] = cc[base + 15] = 1.0
+    return cc
+
+
+def test_kat_sizelist_65x65(O):
+    verts = np.array([[-0.5, -0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.5, 0.5]], np.float32)
+    faces = np.array([[0, 1, 2]], np.int32)
+    g = O.grid_perspective(ident_cam(), faces, verts, 128, 128)
+    assert int(g["sizes"][0]) == 65 * 65 == 4225 and g["R"] == 4225
+    assert list(g["rng"]) == [32, 96, 32, 96]
+    # x-major fill order, key = gx*128 + gy (grid_kernel.cu:318-325)
+    assert g["keys"][0] == 32 * 128 + 32 and g["keys"][-1] == 96 * 128 + 96 and g["used"] == 4225
+
+
+CAM = dict(eye=(0, 0, 0), look=(0, 0, -1), up=(0, 1, 0), near=0.1, far=100.0)
+
+
+def test_kat_centre_tile_triangle_at_z_minus_5(O):
+    W = H = 1024
+    cam = O.cam_from(CAM, 45.0, 1.0)
+    verts = np.array([[-50, -50, -5], [50, -50, -5], [0, 50, -5]], np.float32)
+    faces = np.array([[0, 1, 2]], np.int32)
+    g = O.grid_perspective(cam.cc, faces, verts, 128, 128)
+    out = O.trace_primary(cam, W, H, g, verts, faces, rows=(64, 65))
+    ids = out["id"].reshape(H, W)[512:520, 512:520]
+    t = out["t"].reshape(H, W)[512:520, 512:520]
+    n = out["normal"].reshape(H, W, 3)[512:520, 512:520]
+    d = out["dir"].reshape(H, W, 3)[512:520, 512:520]
+    assert (ids == 0).all() and ids.size == 64
+    assert t[0, 0] == np.float32(5.0)
+    np.testing.assert_array_equal(d[0, 0], np.array([0, 0, -1], np.float32))
+    np.testing.assert_allclose(n.reshape(-1, 3), np.tile([0, 0, 1.0], (64, 1)), atol=1e-6)
+    np.testing.assert_allclose(t * -d[..., 2], 5.0, atol=2e-6)
+
+
+def test_kat_backward_ray_abs_vs_signed(O):
+    """A triangle BEHIND the origin at distance 1: the primary test (|t|) reports a ghost hit at t=+1
+    (trace_kernel.cu:35), the shadow test (signed t = -1 < 999999.9) counts it as an occluder (light_kernel.cu:43-47)."""
+    W = H = 64
+    cam = O.cam_from(CAM, 45.0, 1.0)
+    verts = np.array([[-50, -50, 1], [50, -50, 1], [0, 50, 1]], np.float32)
+    faces = np.array([[0, 1, 2]], np.int32)
+    g = O.grid_perspective(cam.cc, faces, verts, 8, 8)
+    out = O.trace_primary(cam, W, H, g, verts, faces)
+    assert out["id"].reshape(H, W)[32, 32] == 0 and out["t"].reshape(H, W)[32, 32] == np.float32(1.0)
+    # shadow: light at the origin (cam block = light), one ray to the point (0,0,-5); one light cell holding the triangle
+    N = 64
+    t = np.full(N, 5.0, np.float32)
+    dirs = np.tile(np.array([0, 0, -1], np.float32), N)
+    d_map = O.map_rays(cam.cc, t, dirs, np.zeros(3, np.float32), 2, 2, 0, N)
+    prefix, nchunks = O.process_rays(d_map, N, 5, 16)
+    assert nchunks == 1 and prefix[0] == 0
+    cell = int(d_map[N])
+    span = np.zeros(4, np.uint32)
+    offset = np.zeros(4, np.uint32)
+    span[cell] = 1
+    lgrid = dict(vals=np.zeros(1, np.uint32), span=span, offset=offset)
+    sh = np.zeros(N, np.int32)
+    tests, _ = O.trace_shadow(cam.cc, lgrid, 4, verts, faces, t, dirs, sh, d_map, prefix, np.zeros(3, np.float32),
+                              nchunks, 64, N, strict=False)
+    assert sh.sum() == N and tests == N
+    # strict launch: block b takes chunk b-1 and the last chunk is never traced (light_kernel.cu:76-85)
+    sh2 = np.zeros(N, np.int32)
+    O.trace_shadow(cam.cc, lgrid, 4, verts, faces, t, dirs, sh2, d_map, prefix, np.zeros(3, np.float32), nchunks, 64,
+                   N, strict=True)
+    assert sh2.sum() == 0
+
+
+def test_fmath_contract(O):
+    import ctypes as C
+    import subprocess
+    import os
+    import tempfile
+
+    src = r'''
+#include <stdio.h>
+#include <math.h>
+#include "ugrt_fmath.h"
+int main(void){ double worst=0; for (int i=-1000000;i<=1000000;i++){ float x=(float)i*1e-6f; float a=ugrt_acosf(x);
+ double r=acos((double)x); float rf=(float)r; double ulp=fabs((double)a-r)/(double)(nextafterf(rf,10)-rf); if(ulp>worst)worst=ulp;}
+ printf("%g %d %d %u %u %g %g %d\n", worst, ugrt_f2i(NAN), ugrt_f2i(-2.9f), ugrt_f2u(-1.0f), ugrt_f2u(3.9f),
+   (double)ugrt_floorf(-0.5f), (double)ugrt_acosf(1.0000001f), ugrt_floor2i(-3.0f)); return 0; }
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "include"), "t.c", "-o", "t", "-lm"],
+                       cwd=d, check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert float(out[0]) < 1.5  # ulp
+    assert out[1:5] == ["0", "-2", "0", "3"] and out[5] == "-1" and out[6] in ("nan", "-nan") and out[7] == "-3"

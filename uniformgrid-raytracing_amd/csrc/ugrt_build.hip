@@ -21,6 +21,25 @@ struct Rng {
 
 #define BUILD_THREADS 256
 
+// Triangle records for the tracers: {v0, e1 = v1 - v0, e2 = v2 - v0, 0,0,0}, the same
+// subtractions the reference does while staging (trace_kernel.cu:159-169, light_kernel.cu:131-142),
+// done once per build instead of once per (cell, triangle) reference.
+__global__ __launch_bounds__(BUILD_THREADS) void k_tri_records(const int *__restrict__ faces,
+								const float *__restrict__ verts, int F,
+								float4 *__restrict__ rec)
+{
+	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (f >= F)
+		return;
+	int i1 = 3 * faces[f * 3 + 0], i2 = 3 * faces[f * 3 + 1], i3 = 3 * faces[f * 3 + 2];
+	float v0x = verts[i1], v0y = verts[i1 + 1], v0z = verts[i1 + 2];
+	float e1x = verts[i2] - v0x, e1y = verts[i2 + 1] - v0y, e1z = verts[i2 + 2] - v0z;
+	float e2x = verts[i3] - v0x, e2y = verts[i3 + 1] - v0y, e2z = verts[i3 + 2] - v0z;
+	rec[f * 3 + 0] = make_float4(v0x, v0y, v0z, e1x);
+	rec[f * 3 + 1] = make_float4(e1y, e1z, e2x, e2y);
+	rec[f * 3 + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+}
+
 // DSKernel, grid_kernel.cu:164-243 (+ the band clamp of the multi-GPU split)
 __global__ __launch_bounds__(BUILD_THREADS) void k_count_persp(CamBlock cam, const int *__restrict__ faces,
 								const float *__restrict__ verts, int F,
@@ -291,6 +310,16 @@ static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const f
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.sizes, (size_t)F * 4)))
 		return rc;
+	// the geometry may have changed since the last build (animation, a new frame file): refresh the records
+	ctx->rec_valid = false;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->trirec, (size_t)F * 48)))
+		return rc;
+	hipLaunchKernelGGL(k_tri_records, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
+			   ctx->stream, d_facelist, d_vertlist, F, (float4 *)ctx->trirec.p);
+	UGRT_HIP(hipGetLastError());
+	ctx->rec_verts = d_vertlist;
+	ctx->rec_tris = d_facelist;
+	ctx->rec_valid = true;
 	return UGRT_OK;
 }
 

@@ -128,6 +128,7 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 		buf_free(G.cstart);
 	}
 	buf_free(ctx->temp);
+	buf_free(ctx->trirec);
 	buf_free(ctx->witems);
 	buf_free(ctx->wcount);
 	buf_free(ctx->wscan);

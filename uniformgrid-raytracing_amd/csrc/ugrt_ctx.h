@@ -48,6 +48,12 @@ struct ugrt_ctx {
 	int p0 = 0, npix = 0; // first pixel and pixel count of this context's band
 	Grid grid[3];
 	DevBuf temp;                  // rocPRIM temporary storage
+	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
+	// gather ONE record per reference instead of 3 indices + 3 vertices
+	DevBuf trirec;
+	const float *rec_verts = nullptr;
+	const int *rec_tris = nullptr;
+	bool rec_valid = false;
 	DevBuf witems, wcount, wscan; // tracer work lists
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)

@@ -604,6 +604,7 @@ extern "C" int ugrt_animate(ugrt_ctx *ctx, float *d_vertlist, const float *d_ori
 		return UGRT_OK;
 	float c, s;
 	ugrt_rot_cos_sin(rot_factor, &c, &s);
+	ctx->rec_valid = false; // vertices change: the triangle records are stale until the next grid build
 	UGRT_HIP(hipSetDevice(ctx->device));
 	ugrt_prof_begin(ctx, UGRT_ST_ANIMATE);
 	hipLaunchKernelGGL(k_animate, dim3((size + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, ctx->stream,

@@ -163,14 +163,146 @@ __device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const Primar
 	o.ray_dir[pixelID * 3 + 2] = dir[2];
 }
 
+// ---------------------------------------------------------------------------
+// Packet culling.  All 64 rays of a work item share one origin (the eye, or the light), so for
+// a triangle {tvec, e1, e2} the three Moller-Trumbore numerators are LINEAR in the direction d:
+//   det = d.(e2 x e1)   A = u*det = d.(e2 x tvec)   B = v*det = d.(tvec x e1)
+// A hit needs A/det >= 0, B/det >= 0, (A+B)/det <= 1.  Interval arithmetic over the bounding box
+// of the item's directions shows "no lane can pass" for most triangles of a cell list (the
+// lists come from clamped bounding boxes); only survivors get the per-lane test.
+// One LANE culls one TRIANGLE, so a batch of 64 is culled for the price of one per-lane test.
+// The margins (2^-16 relative to the operand magnitudes, against rounding errors of ~2^-22)
+// make the cull strictly conservative: a culled triangle fails the exact float test of
+// intersectTriUV / intersectTri on every lane, so results do not change by a bit.
+// ---------------------------------------------------------------------------
+struct DirBox {
+	float lo[3], hi[3];
+};
+
+__device__ __forceinline__ float d_wave_min(float v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		v = fminf(v, __shfl_xor(v, m));
+	return v;
+}
+__device__ __forceinline__ float d_wave_max(float v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		v = fmaxf(v, __shfl_xor(v, m));
+	return v;
+}
+
+// box of the directions of the lanes with `valid`; other lanes do not contribute
+__device__ __forceinline__ DirBox d_dir_box(const float *d, bool valid)
+{
+	DirBox bx;
+	const float inf = __builtin_huge_valf();
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		bx.lo[k] = d_wave_min(valid ? d[k] : inf);
+		bx.hi[k] = d_wave_max(valid ? d[k] : -inf);
+	}
+	return bx;
+}
+
+__device__ __forceinline__ void d_interval_dot(const float *n, const DirBox &bx, float *fmin, float *fmax)
+{
+	float mn = 0.0f, mx = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		float p = n[k] * bx.lo[k], q = n[k] * bx.hi[k];
+		mn += fminf(p, q);
+		mx += fmaxf(p, q);
+	}
+	*fmin = mn;
+	*fmax = mx;
+}
+
+// true = no direction inside the box can hit the triangle
+__device__ __forceinline__ bool d_cull(const float *tv, const float *e1, const float *e2, const DirBox &bx)
+{
+	float nA[3], nB[3], nD[3], nC[3];
+	D_CROSS(nA, e2, tv);
+	D_CROSS(nB, tv, e1);
+	D_CROSS(nD, e2, e1);
+	const float a = fmaxf(fmaxf(fabsf(tv[0]), fabsf(tv[1])), fabsf(tv[2]));
+	const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
+	const float c = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
+	const float K = 6.0f / 65536.0f;
+	const float mA = fmaxf(K * a * c, 1e-25f), mB = fmaxf(K * a * b, 1e-25f), mD = fmaxf(K * b * c, 1e-25f);
+	float Dmin, Dmax, lo, hi;
+	d_interval_dot(nD, bx, &Dmin, &Dmax);
+	if (!(Dmax < 1e15f && Dmin > -1e15f))
+		return false;
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		nC[k] = nA[k] + nB[k] - nD[k];
+	if (Dmin > mD) { // det > 0 on every lane
+		d_interval_dot(nA, bx, &lo, &hi);
+		if (hi < -mA)
+			return true; // u < 0
+		d_interval_dot(nB, bx, &lo, &hi);
+		if (hi < -mB)
+			return true; // v < 0
+		d_interval_dot(nC, bx, &lo, &hi);
+		return lo > mA + mB + mD; // u + v > 1
+	}
+	if (Dmax < -mD) { // det < 0 on every lane
+		d_interval_dot(nA, bx, &lo, &hi);
+		if (lo > mA)
+			return true;
+		d_interval_dot(nB, bx, &lo, &hi);
+		if (lo > mB)
+			return true;
+		d_interval_dot(nC, bx, &lo, &hi);
+		return hi < -(mA + mB + mD);
+	}
+	return false;
+}
+
+// one triangle as {origin - v0, v1 - v0, v2 - v0}: from the 48-B record, or gathered as the
+// reference does (trace_kernel.cu:151-175) when the caller's arrays are not the ones last built
+template <bool REC>
+__device__ __forceinline__ void d_load_triangle(const float4 *__restrict__ rec, const float *__restrict__ verts,
+						const int *__restrict__ tris, u32 face, float ox, float oy, float oz,
+						float *t9)
+{
+	if (REC) {
+		const float4 a = rec[face * 3 + 0], b = rec[face * 3 + 1], c = rec[face * 3 + 2];
+		t9[0] = ox - a.x;
+		t9[1] = oy - a.y;
+		t9[2] = oz - a.z;
+		t9[3] = a.w;
+		t9[4] = b.x;
+		t9[5] = b.y;
+		t9[6] = b.z;
+		t9[7] = b.w;
+		t9[8] = c.x;
+	} else {
+		d_stage_triangle(verts, tris, face, ox, oy, oz, t9);
+	}
+}
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ u32 d_rank_in_mask(unsigned long long mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+
+#define SURV_CAP 128 // survivors buffered in LDS before the per-lane tests run (flush at >= 64)
+
+template <bool REC>
 __global__ __launch_bounds__(64) void k_trace_primary(CamBlock cam, const float *__restrict__ tex,
 						       const WItem *__restrict__ items,
 						       const u32 *__restrict__ nitems_p,
 						       const u32 *__restrict__ value_list,
 						       const float *__restrict__ verts, const int *__restrict__ tris,
-						       PrimaryOut out, u64 *__restrict__ best, int p0)
+						       const float4 *__restrict__ rec, PrimaryOut out,
+						       u64 *__restrict__ best, int p0)
 {
-	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
+	__shared__ __attribute__((aligned(16))) float lds[SURV_CAP * TRI_STRIDE];
 	const int lane = threadIdx.x;
 	const u32 nitems = *nitems_p;
 	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
@@ -181,30 +313,45 @@ __global__ __launch_bounds__(64) void k_trace_primary(CamBlock cam, const float 
 		const int pixelID = row * cam.W + col;
 		float dir[3];
 		d_ray_dir(cam, tex, col, row, dir);
+		const DirBox box = d_dir_box(dir, true);
 		float oldt = 99999999.9f;
 		u32 ref = 0xFFFFFFFFu;
-		for (u32 b = 0; b < w.count; b += 64) {
-			const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
-			__syncthreads(); // the previous batch has been consumed
-			if ((u32)lane < cnt) {
+		u32 nsurv = 0;
+		for (u32 b = 0; b < w.count || nsurv; b += 64) {
+			if (b < w.count) {
+				// lane = triangle: load, cull against the tile's direction box, keep survivors in list order
+				const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
+				bool keep = false;
 				float t9[9];
-				d_stage_triangle(verts, tris, value_list[w.begin + b + lane], ex, ey, ez, t9);
-				float4 *dst = reinterpret_cast<float4 *>(&lds[lane * TRI_STRIDE]);
-				dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
-				dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
-				dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
+				if ((u32)lane < cnt) {
+					d_load_triangle<REC>(rec, verts, tris, value_list[w.begin + b + lane], ex, ey, ez, t9);
+					keep = !d_cull(&t9[0], &t9[3], &t9[6], box);
+				}
+				const unsigned long long mask = __ballot(keep);
+				if (keep) {
+					float4 *dst = reinterpret_cast<float4 *>(&lds[(nsurv + d_rank_in_mask(mask)) * TRI_STRIDE]);
+					dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
+					dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
+					dst[2] = make_float4(t9[8], __uint_as_float(w.begin + b + lane), 0.0f, 0.0f);
+				}
+				nsurv += (u32)__popcll(mask);
+				if (nsurv < 64u && b + 64 < w.count)
+					continue; // keep collecting
 			}
+			// lane = pixel: the exact per-ray test of the reference on the survivors
 			__syncthreads();
-			for (u32 k = 0; k < cnt; k++) {
+			for (u32 k = 0; k < nsurv; k++) {
 				const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
 				const float4 a = src[0], c = src[1], e = src[2];
 				const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
 				const float v = d_intersect_tri_uv(tv, e1, e2, dir, oldt);
 				if (v != 0.0f) {
 					oldt = v;
-					ref = w.begin + b + k;
+					ref = __float_as_uint(e.y);
 				}
 			}
+			__syncthreads();
+			nsurv = 0;
 		}
 		if (!w.multi) {
 			d_finish_pixel(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris);
@@ -305,9 +452,17 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	UGRT_HIP(hipGetLastError());
 	PrimaryOut out = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_PRIMARY);
-	hipLaunchKernelGGL(k_trace_primary, dim3(launch_blocks_for((u32)cap)), dim3(64), 0, st, ctx->cam,
-			   (const float *)ugrt_ctx_tex(ctx), (const WItem *)items, (const u32 *)(incl + (ncell - 1)),
-			   d_value_list, d_vertlist, d_trilist, out, (u64 *)ctx->best.p, ctx->p0);
+	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
+	if (use_rec)
+		hipLaunchKernelGGL(k_trace_primary<true>, dim3(launch_blocks_for((u32)cap)), dim3(64), 0, st, ctx->cam,
+				   (const float *)ugrt_ctx_tex(ctx), (const WItem *)items,
+				   (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist,
+				   (const float4 *)ctx->trirec.p, out, (u64 *)ctx->best.p, ctx->p0);
+	else
+		hipLaunchKernelGGL(k_trace_primary<false>, dim3(launch_blocks_for((u32)cap)), dim3(64), 0, st, ctx->cam,
+				   (const float *)ugrt_ctx_tex(ctx), (const WItem *)items,
+				   (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist,
+				   (const float4 *)nullptr, out, (u64 *)ctx->best.p, ctx->p0);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
@@ -323,16 +478,18 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 // ---------------------------------------------------------------------------
 // shadow rays: mod_light_rckernel, light_kernel.cu:52-270 (cam = LIGHT camera)
 // ---------------------------------------------------------------------------
+template <bool REC>
 __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *__restrict__ items,
 						      const u32 *__restrict__ nitems_p,
 						      const u32 *__restrict__ curflist, const float *__restrict__ verts,
-						      const int *__restrict__ tris, const float *__restrict__ t_value_list,
+						      const int *__restrict__ tris, const float4 *__restrict__ rec,
+						      const float *__restrict__ t_value_list,
 						      const float *__restrict__ ray_direction_list,
 						      int *__restrict__ is_shadowed, const u32 *__restrict__ d_map,
 						      const u32 *__restrict__ prefix, u32 nchunks, u32 n,
 						      const float *__restrict__ cmPt)
 {
-	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
+	__shared__ __attribute__((aligned(16))) float lds[SURV_CAP * TRI_STRIDE];
 	const int lane = threadIdx.x;
 	const u32 nitems = *nitems_p;
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
@@ -360,22 +517,33 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *
 						     (pI[2] - lz) * (pI[2] - lz));
 			D_NORMALIZE(rd);
 		}
+		const DirBox box = d_dir_box(rd, have_ray);
 		bool done = !have_ray; // rayDoneMap == 2
 		bool hit = false;
-		for (u32 b = 0; b < w.count; b += 64) {
-			const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
-			__syncthreads();
-			if ((u32)lane < cnt) {
+		u32 nsurv = 0;
+		for (u32 b = 0; b < w.count || nsurv; b += 64) {
+			if (b < w.count) {
+				const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
+				bool keep = false;
 				float t9[9];
-				d_stage_triangle(verts, tris, curflist[w.begin + b + lane], lx, ly, lz, t9);
-				float4 *dst = reinterpret_cast<float4 *>(&lds[lane * TRI_STRIDE]);
-				dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
-				dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
-				dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
+				if ((u32)lane < cnt) {
+					d_load_triangle<REC>(rec, verts, tris, curflist[w.begin + b + lane], lx, ly, lz, t9);
+					keep = !d_cull(&t9[0], &t9[3], &t9[6], box);
+				}
+				const unsigned long long mask = __ballot(keep);
+				if (keep) {
+					float4 *dst = reinterpret_cast<float4 *>(&lds[(nsurv + d_rank_in_mask(mask)) * TRI_STRIDE]);
+					dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
+					dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
+					dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
+				}
+				nsurv += (u32)__popcll(mask);
+				if (nsurv < 64u && b + 64 < w.count)
+					continue;
 			}
 			__syncthreads();
 			if (!done) {
-				for (u32 k = 0; k < cnt; k++) {
+				for (u32 k = 0; k < nsurv; k++) {
 					const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
 					const float4 a = src[0], c = src[1], e = src[2];
 					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y },
@@ -398,6 +566,8 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *
 					}
 				}
 			}
+			__syncthreads();
+			nsurv = 0;
 			// the whole beam is decided: skip the remaining triangle batches
 			if (__ballot(!done) == 0ull)
 				break;
@@ -467,9 +637,17 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
-	hipLaunchKernelGGL(k_trace_shadow, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
-			   (const WItem *)items, (const u32 *)(incl + (traced - 1)), d_value_list, d_vertlist, d_trilist,
-			   d_t_value, d_ray_dir, d_is_shadowed, d_map, d_prefix_map, num_chunks, n, d_cam_position);
+	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
+	if (use_rec)
+		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
+				   (const WItem *)items, (const u32 *)(incl + (traced - 1)), d_value_list, d_vertlist,
+				   d_trilist, (const float4 *)ctx->trirec.p, d_t_value, d_ray_dir, d_is_shadowed, d_map,
+				   d_prefix_map, num_chunks, n, d_cam_position);
+	else
+		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
+				   (const WItem *)items, (const u32 *)(incl + (traced - 1)), d_value_list, d_vertlist,
+				   d_trilist, (const float4 *)nullptr, d_t_value, d_ray_dir, d_is_shadowed, d_map,
+				   d_prefix_map, num_chunks, n, d_cam_position);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

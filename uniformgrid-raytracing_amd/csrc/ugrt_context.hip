@@ -140,6 +140,15 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->rstart);
 	buf_free(ctx->cchunks);
 	buf_free(ctx->cbase);
+	buf_free(ctx->skey[0]);
+	buf_free(ctx->skey[1]);
+	buf_free(ctx->sval[0]);
+	buf_free(ctx->sval[1]);
+	buf_free(ctx->sdesc);
+	buf_free(ctx->sstart);
+	buf_free(ctx->send);
+	buf_free(ctx->scnt);
+	buf_free(ctx->sbase);
 	if (ctx->h_pinned)
 		(void)hipHostFree(ctx->h_pinned);
 	if (ctx->d_small)

@@ -58,6 +58,7 @@ struct ugrt_ctx {
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)
 	DevBuf rspan, roffset, rstart, cchunks, cbase; // ray runs per light cell
+	DevBuf skey[2], sval[2], sdesc, sstart, send, scnt, sbase; // shadow tracer's private ray re-grouping
 	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
 	u32 *d_small = nullptr;       // 16 u32 of device scratch (totals)
 	bool prof_on = false;
@@ -85,5 +86,7 @@ int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
 // stable LSD radix sort of (key,value) pairs on key bits [0,end_bit)
 int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
 			 int end_bit);
+int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,
+			   int end_bit);
 
 #endif

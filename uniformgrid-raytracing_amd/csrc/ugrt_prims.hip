@@ -58,3 +58,24 @@ int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vi
 					   ctx->stream));
 	return UGRT_OK;
 }
+
+// 64-bit keys: the shadow tracer's private re-grouping of rays (light cell, direction Morton code)
+int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,
+			   int end_bit)
+{
+	if (n == 0)
+		return UGRT_OK;
+	if (end_bit < 1)
+		end_bit = 1;
+	if (end_bit > 64)
+		end_bit = 64;
+	size_t bytes = 0;
+	UGRT_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, (unsigned)end_bit,
+					   ctx->stream));
+	int rc = ugrt_buf_reserve(ctx, ctx->temp, bytes);
+	if (rc)
+		return rc;
+	UGRT_HIP(rocprim::radix_sort_pairs(ctx->temp.p, bytes, kin, kout, vin, vout, n, 0u, (unsigned)end_bit,
+					   ctx->stream));
+	return UGRT_OK;
+}

@@ -64,46 +64,6 @@ __global__ __launch_bounds__(WL_THREADS) void k_wl_fill_primary(const u32 *__res
 	}
 }
 
-// shadow: one entry per traced chunk; the chunk's light cell is the sorted key
-// of its first ray (light_kernel.cu:111); the sentinel cell has no triangles
-__global__ __launch_bounds__(WL_THREADS) void k_wl_count_shadow(const u32 *__restrict__ span, u32 C,
-								 const u32 *__restrict__ map, u32 n,
-								 const u32 *__restrict__ prefix, u32 nchunk_traced,
-								 u32 *__restrict__ cnt)
-{
-	u32 k = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (k >= nchunk_traced)
-		return;
-	u32 cell = map[n + prefix[k]];
-	u32 sp = cell < C ? span[cell] : 0u;
-	cnt[k] = (sp + SEG - 1) / SEG; // 0 triangles: nothing can shadow these rays
-}
-
-__global__ __launch_bounds__(WL_THREADS) void k_wl_fill_shadow(const u32 *__restrict__ span,
-								const u32 *__restrict__ offset, u32 C,
-								const u32 *__restrict__ map, u32 n,
-								const u32 *__restrict__ prefix, u32 nchunk_traced,
-								const u32 *__restrict__ cnt, const u32 *__restrict__ incl,
-								WItem *__restrict__ items)
-{
-	u32 k = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (k >= nchunk_traced)
-		return;
-	u32 cell = map[n + prefix[k]];
-	u32 sp = cell < C ? span[cell] : 0u;
-	u32 off = cell < C ? offset[cell] : 0u;
-	u32 m = cnt[k], base = incl[k] - m;
-	for (u32 s = 0; s < m; s++) {
-		WItem w;
-		w.cell = k;
-		w.begin = off + s * SEG;
-		u32 left = sp - s * SEG;
-		w.count = left < SEG ? left : SEG;
-		w.multi = 0;
-		items[base + s] = w;
-	}
-}
-
 // ---------------------------------------------------------------------------
 // primary rays: rckernel_alpha, trace_kernel.cu:84-270 (NUM_SLABS = 1)
 // ---------------------------------------------------------------------------
@@ -223,6 +183,9 @@ __device__ __forceinline__ void d_interval_dot(const float *n, const DirBox &bx,
 // true = no direction inside the box can hit the triangle
 __device__ __forceinline__ bool d_cull(const float *tv, const float *e1, const float *e2, const DirBox &bx)
 {
+#ifdef UGRT_DEBUG_CULL_ALL
+	return (tv[0] + tv[1] + tv[2] + e1[0] + e1[1] + e1[2] + e2[0] + e2[1] + e2[2]) != 12345.678f;
+#endif
 	float nA[3], nB[3], nD[3], nC[3];
 	D_CROSS(nA, e2, tv);
 	D_CROSS(nB, tv, e1);
@@ -478,15 +441,133 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 // ---------------------------------------------------------------------------
 // shadow rays: mod_light_rckernel, light_kernel.cu:52-270 (cam = LIGHT camera)
 // ---------------------------------------------------------------------------
+// Which sorted rays the reference traces: chunks [0, traced) = sorted rays [0, M) with
+// M = prefix[traced] (or n when every chunk is traced).  Inside that set the grouping of rays is
+// free: each ray's flag only depends on its own light cell's triangle list.  The reference's
+// chunks are 64 consecutive rays in PIXEL order inside a cell, i.e. spread over the whole cell;
+// here the traced rays of a cell are re-grouped by a Morton code of their direction from the
+// light, so that a wave's 64 rays form a narrow beam and the packet cull removes almost every
+// triangle of the cell's list before any per-ray test.  d_map / prefix (the reference-visible
+// arrays) are not modified.
+struct SItem {
+	u32 ray_start; // into the re-grouped ray list
+	u32 ray_count; // <= 64
+	u32 tri_begin; // into the light grid's value list
+	u32 tri_count; // <= SEG
+};
+
+__device__ __forceinline__ u32 d_spread10(u32 v)
+{
+	v &= 0x3FFu;
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+
+__global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const float *__restrict__ t_value_list,
+							     const float *__restrict__ ray_direction_list,
+							     const u32 *__restrict__ d_map, const u32 *__restrict__ prefix,
+							     u32 nchunks, u32 traced, u32 n, u32 C,
+							     const float *__restrict__ cmPt, u64 *__restrict__ keys,
+							     u32 *__restrict__ vals)
+{
+	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (i >= n)
+		return;
+	const u32 M = traced < nchunks ? prefix[traced] : n;
+	const u32 pixel = d_map[i];
+	u32 cell = d_map[n + i];
+	u32 code = 0;
+	if (i >= M) {
+		cell = C + 1; // not traced by the reference's launch
+	} else if (cell >= C) {
+		cell = C; // sentinel cell: no triangle list
+	} else {
+		float tVal = t_value_list[pixel];
+		float rd[3];
+		rd[0] = (cmPt[0] + tVal * ray_direction_list[pixel * 3 + 0]) - cam.cc[0];
+		rd[1] = (cmPt[1] + tVal * ray_direction_list[pixel * 3 + 1]) - cam.cc[1];
+		rd[2] = (cmPt[2] + tVal * ray_direction_list[pixel * 3 + 2]) - cam.cc[2];
+		D_NORMALIZE(rd);
+		u32 q[3];
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			float f = (rd[k] * 0.5f + 0.5f) * 1023.0f;
+			f = f > 0.0f ? f : 0.0f; // also drops NaN
+			q[k] = f < 1023.0f ? (u32)f : 1023u;
+		}
+		code = d_spread10(q[0]) | (d_spread10(q[1]) << 1) | (d_spread10(q[2]) << 2);
+	}
+	keys[i] = ((u64)cell << 30) | (u64)code;
+	vals[i] = pixel;
+}
+
+__global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const u64 *__restrict__ keys, u32 n, u32 *__restrict__ rstart,
+							     u32 *__restrict__ rend)
+{
+	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (i >= n)
+		return;
+	u32 c = (u32)(keys[i] >> 30);
+	if (i == 0 || (u32)(keys[i - 1] >> 30) != c)
+		rstart[c] = i;
+	if (i == n - 1 || (u32)(keys[i + 1] >> 30) != c)
+		rend[c] = i + 1;
+}
+
+// items of light cell c = (64-ray groups of c) x (SEG-triangle segments of c); cells without rays or
+// without triangles need no work at all
+__global__ __launch_bounds__(WL_THREADS) void k_shadow_count(const u32 *__restrict__ span, const u32 *__restrict__ rstart,
+							      const u32 *__restrict__ rend, u32 C, u32 *__restrict__ cnt)
+{
+	u32 c = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (c >= C)
+		return;
+	u32 rays = rend[c] - rstart[c];
+	cnt[c] = ((rays + 63u) / 64u) * ((span[c] + SEG - 1) / SEG);
+}
+
+__global__ __launch_bounds__(WL_THREADS) void k_shadow_items(const u32 *__restrict__ span, const u32 *__restrict__ offset,
+							      const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
+							      const u32 *__restrict__ incl, u32 C, SItem *__restrict__ items)
+{
+	const u32 total = incl[C - 1];
+	u32 it = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (it >= total)
+		return;
+	u32 lo = 0, hi = C - 1; // smallest c with incl[c] > it
+	while (lo < hi) {
+		u32 mid = (lo + hi) >> 1;
+		if (incl[mid] > it)
+			hi = mid;
+		else
+			lo = mid + 1;
+	}
+	const u32 c = lo;
+	const u32 nseg = (span[c] + SEG - 1) / SEG;
+	const u32 ngrp = (rend[c] - rstart[c] + 63u) / 64u;
+	const u32 local = it - (incl[c] - nseg * ngrp);
+	const u32 j = local / nseg, sg = local % nseg;
+	SItem w;
+	w.ray_start = rstart[c] + 64u * j;
+	u32 rleft = rend[c] - w.ray_start;
+	w.ray_count = rleft < 64u ? rleft : 64u;
+	w.tri_begin = offset[c] + sg * SEG;
+	u32 tleft = span[c] - sg * SEG;
+	w.tri_count = tleft < SEG ? tleft : SEG;
+	items[it] = w;
+}
+
 template <bool REC>
-__global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *__restrict__ items,
+__global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const SItem *__restrict__ items,
 						      const u32 *__restrict__ nitems_p,
 						      const u32 *__restrict__ curflist, const float *__restrict__ verts,
 						      const int *__restrict__ tris, const float4 *__restrict__ rec,
 						      const float *__restrict__ t_value_list,
 						      const float *__restrict__ ray_direction_list,
-						      int *__restrict__ is_shadowed, const u32 *__restrict__ d_map,
-						      const u32 *__restrict__ prefix, u32 nchunks, u32 n,
+						      int *__restrict__ is_shadowed, const u32 *__restrict__ ray_pixels,
 						      const float *__restrict__ cmPt)
 {
 	__shared__ __attribute__((aligned(16))) float lds[SURV_CAP * TRI_STRIDE];
@@ -495,15 +576,14 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
 	const float cx = cmPt[0], cy = cmPt[1], cz = cmPt[2];
 	for (u32 it = blockIdx.x; it < nitems; it += gridDim.x) {
-		const WItem w = items[it];
-		const u32 start = prefix[w.cell];
-		const u32 end = (w.cell + 1 < nchunks) ? prefix[w.cell + 1] : n;
-		const bool have_ray = start + (u32)lane < end;
+		const SItem w = items[it];
+		const bool have_ray = (u32)lane < w.ray_count;
 		int pseudoPixelId = 0;
 		float rd[3] = { 0.0f, 0.0f, 1.0f }, distance_b = 0.0f;
+		bool done = true; // rayDoneMap == 2
 		if (have_ray) {
 			// light_kernel.cu:166-184
-			pseudoPixelId = (int)d_map[start + lane];
+			pseudoPixelId = (int)ray_pixels[w.ray_start + lane];
 			float tVal = t_value_list[pseudoPixelId];
 			float pI[3];
 			pI[0] = cx + tVal * ray_direction_list[pseudoPixelId * 3 + 0];
@@ -516,18 +596,22 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *
 			distance_b = __builtin_sqrtf((pI[0] - lx) * (pI[0] - lx) + (pI[1] - ly) * (pI[1] - ly) +
 						     (pI[2] - lz) * (pI[2] - lz));
 			D_NORMALIZE(rd);
+			// a ray already flagged by another segment of its cell needs no more tests
+			done = is_shadowed[pseudoPixelId] == 1;
 		}
-		const DirBox box = d_dir_box(rd, have_ray);
-		bool done = !have_ray; // rayDoneMap == 2
+		const bool active = have_ray && !done;
+		if (__ballot(active) == 0ull)
+			continue;
+		const DirBox box = d_dir_box(rd, active);
 		bool hit = false;
 		u32 nsurv = 0;
-		for (u32 b = 0; b < w.count || nsurv; b += 64) {
-			if (b < w.count) {
-				const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
+		for (u32 b = 0; b < w.tri_count || nsurv; b += 64) {
+			if (b < w.tri_count) {
+				const u32 cnt = (w.tri_count - b) < 64u ? (w.tri_count - b) : 64u;
 				bool keep = false;
 				float t9[9];
 				if ((u32)lane < cnt) {
-					d_load_triangle<REC>(rec, verts, tris, curflist[w.begin + b + lane], lx, ly, lz, t9);
+					d_load_triangle<REC>(rec, verts, tris, curflist[w.tri_begin + b + lane], lx, ly, lz, t9);
 					keep = !d_cull(&t9[0], &t9[3], &t9[6], box);
 				}
 				const unsigned long long mask = __ballot(keep);
@@ -538,7 +622,7 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *
 					dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
 				}
 				nsurv += (u32)__popcll(mask);
-				if (nsurv < 64u && b + 64 < w.count)
+				if (nsurv < 64u && b + 64 < w.tri_count)
 					continue;
 			}
 			__syncthreads();
@@ -577,6 +661,14 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const WItem *
 	}
 }
 
+static int bits_of(u32 v)
+{
+	int b = 1;
+	while (b < 32 && (1ull << b) < (unsigned long long)v)
+		b++;
+	return b;
+}
+
 // check_for_shadows, per_frame_funcs.h:139-159
 extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, const float *d_vertlist,
 				 const int *d_trilist, const unsigned *d_span, const unsigned *d_offset,
@@ -602,26 +694,46 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		traced = lim ? lim - 1 : 0;
 	}
 	ctx->stats[2] = traced;
-	if (traced == 0)
+	ctx->stats[1] = 0;
+	if (traced == 0 || n == 0)
 		return UGRT_OK;
-	u32 R = 0;
-	int rc = refs_of(ctx, d_span, d_offset, C, &R);
-	if (rc)
+	int rc;
+	for (int i = 0; i < 2; i++) {
+		if ((rc = ugrt_buf_reserve(ctx, ctx->skey[i], (size_t)n * 8)))
+			return rc;
+		if ((rc = ugrt_buf_reserve(ctx, ctx->sval[i], (size_t)n * 4)))
+			return rc;
+	}
+	const u32 ncellk = C + 2; // + sentinel + "not traced"
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sstart, (size_t)ncellk * 4)))
 		return rc;
-	// a cell's triangles are re-read by each of its chunks: items <= sum over chunks of ceil(span/SEG)
-	// bounded by traced + (refs of the busiest case); size from the exact count instead
-	if ((rc = ugrt_buf_reserve(ctx, ctx->wcount, (size_t)traced * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->send, (size_t)ncellk * 4)))
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)traced * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->scnt, (size_t)C * 4)))
 		return rc;
-	u32 *cnt = (u32 *)ctx->wcount.p, *incl = (u32 *)ctx->wscan.p;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sbase, (size_t)C * 4)))
+		return rc;
+	u64 *k0 = (u64 *)ctx->skey[0].p, *k1 = (u64 *)ctx->skey[1].p;
+	u32 *v0 = (u32 *)ctx->sval[0].p, *v1 = (u32 *)ctx->sval[1].p;
+	u32 *rstart = (u32 *)ctx->sstart.p, *rend = (u32 *)ctx->send.p, *cnt = (u32 *)ctx->scnt.p,
+	    *incl = (u32 *)ctx->sbase.p;
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
-	hipLaunchKernelGGL(k_wl_count_shadow, dim3((traced + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   d_span, C, d_map, n, d_prefix_map, traced, cnt);
+	hipLaunchKernelGGL(k_shadow_keys, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, ctx->cam,
+			   d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_cam_position, k0, v0);
 	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_inclusive_scan(ctx, cnt, incl, traced)))
+	if ((rc = ugrt_prim_sort_pairs64(ctx, k0, k1, v0, v1, n, 30 + bits_of(ncellk))))
 		return rc;
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, incl + (traced - 1), 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemsetAsync(rstart, 0, (size_t)ncellk * 4, st));
+	UGRT_HIP(hipMemsetAsync(rend, 0, (size_t)ncellk * 4, st));
+	hipLaunchKernelGGL(k_shadow_runs, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   (const u64 *)k1, n, rstart, rend);
+	UGRT_HIP(hipGetLastError());
+	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
+			   (const u32 *)rstart, (const u32 *)rend, C, cnt);
+	UGRT_HIP(hipGetLastError());
+	if ((rc = ugrt_prim_inclusive_scan(ctx, cnt, incl, C)))
+		return rc;
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, incl + (C - 1), 4, hipMemcpyDeviceToHost, st));
 	UGRT_HIP(hipStreamSynchronize(st));
 	const u32 nitems = ctx->h_pinned[10];
 	ctx->stats[1] = nitems;
@@ -629,25 +741,25 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 		return UGRT_OK;
 	}
-	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, (size_t)nitems * sizeof(WItem))))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sdesc, (size_t)nitems * sizeof(SItem))))
 		return rc;
-	WItem *items = (WItem *)ctx->witems.p;
-	hipLaunchKernelGGL(k_wl_fill_shadow, dim3((traced + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   d_span, d_offset, C, d_map, n, d_prefix_map, traced, cnt, incl, items);
+	SItem *items = (SItem *)ctx->sdesc.p;
+	hipLaunchKernelGGL(k_shadow_items, dim3((nitems + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
+			   d_offset, (const u32 *)rstart, (const u32 *)rend, (const u32 *)incl, C, items);
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
-	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
+	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	if (use_rec)
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
-				   (const WItem *)items, (const u32 *)(incl + (traced - 1)), d_value_list, d_vertlist,
-				   d_trilist, (const float4 *)ctx->trirec.p, d_t_value, d_ray_dir, d_is_shadowed, d_map,
-				   d_prefix_map, num_chunks, n, d_cam_position);
+				   (const SItem *)items, (const u32 *)(incl + (C - 1)), d_value_list, d_vertlist, d_trilist,
+				   (const float4 *)ctx->trirec.p, d_t_value, d_ray_dir, d_is_shadowed, (const u32 *)v1,
+				   d_cam_position);
 	else
 		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
-				   (const WItem *)items, (const u32 *)(incl + (traced - 1)), d_value_list, d_vertlist,
-				   d_trilist, (const float4 *)nullptr, d_t_value, d_ray_dir, d_is_shadowed, d_map,
-				   d_prefix_map, num_chunks, n, d_cam_position);
+				   (const SItem *)items, (const u32 *)(incl + (C - 1)), d_value_list, d_vertlist, d_trilist,
+				   (const float4 *)nullptr, d_t_value, d_ray_dir, d_is_shadowed, (const u32 *)v1,
+				   d_cam_position);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

@@ -274,8 +274,14 @@ def crash(outdir=None, scale=1.0):
                     faces="xXyY")
     static_target = int(round(200000 * scale / 2)) * 2
     left = static_target - mesh.ntris()
-    if left > 0:  # a rug: one strip of quads that brings the static part to the exact count
-        mesh.add(*grid_quad((9, 8.5, 0.01), (11, 0, 0), (0, 9, 0), left // 2, 1), 4)
+    if left > 0:  # a rug that brings the static part to the exact count: near-square quads, not slivers
+        q = left // 2
+        nu = max(1, int((q * 11.0 / 9.0) ** 0.5))
+        nv = max(1, q // nu)
+        mesh.add(*grid_quad((9, 8.5, 0.01), (11, 0, 0), (0, 9, 0), nu, nv), 4)
+        rest = q - nu * nv
+        if rest > 0:  # fringe: `rest` small quads along one edge
+            mesh.add(*grid_quad((9, 8.4, 0.01), (11.0 * rest / max(nu, rest), 0, 0), (0, 0.1, 0), rest, 1), 4)
     n_static_faces, n_static_verts = mesh.ntris(), mesh.nv
     level = 7 if scale >= 1.0 else max(1, int(round(7 + np.log(max(scale, 1e-3)) / np.log(4))))
     sv, sf = icosphere(level)

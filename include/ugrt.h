@@ -17,7 +17,7 @@
  *    ugrt_last_error() describes the failure.  (The reference aborts the
  *    process instead: cutilSafeCall / exit(-1), frustum_grid.h:127-131.)
  *  - all device work is enqueued on the context's stream (ugrt_ctx_set_stream);
- *    functions that must return a host value (ugrt_grid_get_info,
+ *    functions that must return a host value (the grid builders' total_refs,
  *    ugrt_sort_rays' chunk count) synchronise that stream.
  *  - there is NO CPU fallback: a device entry point fails with UGRT_ENODEV
  *    when no HIP device is usable.
@@ -111,7 +111,8 @@ typedef struct ugrt_grid_info {
 	unsigned *d_offset;              /* [num_cells] exclusive scan of d_span */
 	unsigned total_refs;             /* "total_triangles", frustum_grid.h:254 */
 	unsigned num_cells;
-	unsigned cells_used;             /* "Number of actual cells", frustum_grid.h:337 */
+	unsigned cells_used;             /* "Number of actual cells", frustum_grid.h:337; final once the
+					    stream has been synchronised after the build */
 } ugrt_grid_info;
 
 /* ---- library ---------------------------------------------------------- */

@@ -68,6 +68,7 @@ def test_perspective_grid_build(ugrt, O, torch, name, cam, W, H, lg):
     c = ugrt.renderer.make_camera(s["cameras"][cam], 45.0, r.aspect)
     ctx.upload_camera(c.camcoords)
     ctx.grid_build_perspective(r.d_faces, r.d_verts, r.F)
+    ctx.synchronize()
     value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
     g = O.grid_perspective(O.cam_from(s["cameras"][cam], 45.0, r.aspect).cc, s["faces"], s["verts"], W // 8, H // 8)
     assert gi.total_refs == g["R"] and gi.num_cells == (W // 8) * (H // 8) and gi.cells_used == g["used"]

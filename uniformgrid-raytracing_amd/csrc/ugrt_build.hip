@@ -193,8 +193,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ 
 // frustum_grid.h:334) in one pass over the sorted keys: run heads record the
 // run start, run tails the run end; used[0] counts the runs.
 __global__ __launch_bounds__(BUILD_THREADS) void k_bounds(const u32 *__restrict__ keys, u32 R,
-							   u32 *__restrict__ cstart, u32 *__restrict__ cend,
-							   u32 *__restrict__ used)
+							   u32 *__restrict__ cstart, u32 *__restrict__ cend)
 {
 	u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (i >= R)
@@ -202,22 +201,26 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_bounds(const u32 *__restrict_
 	u32 k = keys[i];
 	bool head = (i == 0) || (keys[i - 1] != k);
 	bool tail = (i == R - 1) || (keys[i + 1] != k);
-	if (head) {
+	if (head)
 		cstart[k] = i;
-		atomicAdd(used, 1u);
-	}
 	if (tail)
 		cend[k] = i + 1;
 }
 
-// span = run length (0 for cells without a run: set_as_zero, misc_kernel.cu:26)
+// span = run length (0 for cells without a run: set_as_zero, misc_kernel.cu:26); also counts the
+// occupied cells ("Number of actual cells", frustum_grid.h:337) with one atomic per block
 __global__ __launch_bounds__(BUILD_THREADS) void k_span(const u32 *__restrict__ cstart, u32 *__restrict__ span_io,
-							 u32 C)
+							 u32 C, u32 *__restrict__ used)
 {
 	u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x;
-	if (c >= C)
-		return;
-	span_io[c] = span_io[c] - cstart[c]; // span_io holds the run end on entry
+	u32 sp = 0;
+	if (c < C) {
+		sp = span_io[c] - cstart[c]; // span_io holds the run end on entry
+		span_io[c] = sp;
+	}
+	int cnt = __syncthreads_count(sp != 0);
+	if (threadIdx.x == 0 && cnt)
+		atomicAdd(used, (u32)cnt);
 }
 
 static int bits_for(u32 C)
@@ -281,10 +284,10 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz)
 	UGRT_HIP(hipMemsetAsync(ctx->d_small, 0, 4, st));
 	if (R) {
 		hipLaunchKernelGGL(k_bounds, dim3((R + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)k1, R, (u32 *)G.cstart.p, (u32 *)G.span.p, ctx->d_small);
+				   (const u32 *)k1, R, (u32 *)G.cstart.p, (u32 *)G.span.p);
 		UGRT_HIP(hipGetLastError());
 		hipLaunchKernelGGL(k_span, dim3((C + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)G.cstart.p, (u32 *)G.span.p, C);
+				   (const u32 *)G.cstart.p, (u32 *)G.span.p, C, ctx->d_small);
 		UGRT_HIP(hipGetLastError());
 	}
 	rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C);

@@ -232,7 +232,8 @@ extern "C" int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out)
 	Grid &G = ctx->grid[which];
 	if (!G.valid)
 		return ugrt_fail(UGRT_EINVAL, "grid_get_info: grid %d has not been built", which);
-	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	// pointers and total_refs are known on the host since the build; cells_used is fetched lazily and
+	// is final after the next ugrt_ctx_synchronize (the reference only prints it, frustum_grid.h:338)
 	out->d_triangle_value_list = G.vals;
 	out->d_triangle_key_list = G.keys;
 	out->d_span = (unsigned *)G.span.p;

@@ -16,7 +16,8 @@
 // over the work list, whose length stays on the device.
 #include "ugrt_dev.h"
 
-#define SEG 256u          // triangles per work item
+#define SEG 256u          // triangles per primary work item
+#define SSEG 1024u        // triangles per shadow work item (ray set-up is amortised over 16 batches)
 #define TRI_STRIDE 12     // floats per staged triangle (9 used, 48 B: ds_read_b128 x3)
 #define WL_THREADS 256
 
@@ -453,7 +454,7 @@ struct SItem {
 	u32 ray_start; // into the re-grouped ray list
 	u32 ray_count; // <= 64
 	u32 tri_begin; // into the light grid's value list
-	u32 tri_count; // <= SEG
+	u32 tri_count; // <= SSEG
 };
 
 __device__ __forceinline__ u32 d_spread10(u32 v)
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_count(const u32 *__restri
 	if (c >= C)
 		return;
 	u32 rays = rend[c] - rstart[c];
-	cnt[c] = ((rays + 63u) / 64u) * ((span[c] + SEG - 1) / SEG);
+	cnt[c] = ((rays + 63u) / 64u) * ((span[c] + SSEG - 1) / SSEG);
 }
 
 __global__ __launch_bounds__(WL_THREADS) void k_shadow_items(const u32 *__restrict__ span, const u32 *__restrict__ offset,
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_items(const u32 *__restri
 			lo = mid + 1;
 	}
 	const u32 c = lo;
-	const u32 nseg = (span[c] + SEG - 1) / SEG;
+	const u32 nseg = (span[c] + SSEG - 1) / SSEG;
 	const u32 ngrp = (rend[c] - rstart[c] + 63u) / 64u;
 	const u32 local = it - (incl[c] - nseg * ngrp);
 	const u32 j = local / nseg, sg = local % nseg;
@@ -554,9 +555,9 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_items(const u32 *__restri
 	w.ray_start = rstart[c] + 64u * j;
 	u32 rleft = rend[c] - w.ray_start;
 	w.ray_count = rleft < 64u ? rleft : 64u;
-	w.tri_begin = offset[c] + sg * SEG;
-	u32 tleft = span[c] - sg * SEG;
-	w.tri_count = tleft < SEG ? tleft : SEG;
+	w.tri_begin = offset[c] + sg * SSEG;
+	u32 tleft = span[c] - sg * SSEG;
+	w.tri_count = tleft < SSEG ? tleft : SSEG;
 	items[it] = w;
 }
 
@@ -780,10 +781,11 @@ __device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
 	return d_clampi(c, 0, g.dims[k] - 1);
 }
 
-template <bool COUNT>
+template <bool COUNT, bool REC>
 __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restrict__ value_list,
 						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
 						    const float *__restrict__ verts, const int *__restrict__ tris,
+						    const float4 *__restrict__ rec,
 						    const float *__restrict__ rays, const int *__restrict__ active,
 						    int p0, int npix, float *__restrict__ hit_t, int *__restrict__ hit_id,
 						    unsigned long long *__restrict__ counters)
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 				for (u32 r = 0; r < sp; r++) {
 					u32 f = value_list[off + r];
 					float t9[9], t;
-					d_stage_triangle(verts, tris, f, o[0], o[1], o[2], t9);
+					d_load_triangle<REC>(rec, verts, tris, f, o[0], o[1], o[2], t9);
 					if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
 						best_t = t;
 						best_id = (int)f;
@@ -923,9 +925,9 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		// counting variant (never the timed one): same traversal + three atomics per ray
 		unsigned long long *dc = (unsigned long long *)(ctx->d_small + 8);
 		UGRT_HIP(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), ctx->stream));
-		hipLaunchKernelGGL(k_trace_dda<true>, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
-				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, d_rays, d_active, ctx->p0,
-				   ctx->npix, d_hit_t, d_hit_id, dc);
+		hipLaunchKernelGGL((k_trace_dda<true, false>), dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
+				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, (const float4 *)nullptr, d_rays,
+				   d_active, ctx->p0, ctx->npix, d_hit_t, d_hit_id, dc);
 		UGRT_HIP(hipGetLastError());
 		unsigned long long h[3];
 		UGRT_HIP(hipMemcpyAsync(h, dc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -935,10 +937,16 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		ctx->stats[5] = h[2];
 		return UGRT_OK;
 	}
+	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
-	hipLaunchKernelGGL(k_trace_dda<false>, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
-			   d_value_list, d_span, d_offset, d_vertlist, d_trilist, d_rays, d_active, ctx->p0, ctx->npix,
-			   d_hit_t, d_hit_id, (unsigned long long *)nullptr);
+	if (use_rec)
+		hipLaunchKernelGGL((k_trace_dda<false, true>), dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
+				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, (const float4 *)ctx->trirec.p,
+				   d_rays, d_active, ctx->p0, ctx->npix, d_hit_t, d_hit_id, (unsigned long long *)nullptr);
+	else
+		hipLaunchKernelGGL((k_trace_dda<false, false>), dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
+				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, (const float4 *)nullptr, d_rays,
+				   d_active, ctx->p0, ctx->npix, d_hit_t, d_hit_id, (unsigned long long *)nullptr);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_DDA);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

@@ -11,8 +11,11 @@ from . import lib, check, Config, GridInfo, STAGES, _f3, _P
 
 
 def _ptr(t):
+    """torch tensor -> device pointer; raw pointers (int / c_void_p) pass through."""
     if t is None:
         return None
+    if isinstance(t, (int, C.c_void_p)):
+        return t
     assert t.is_contiguous(), "ugrt: tensors must be contiguous"
     return C.c_void_p(t.data_ptr())
 
@@ -67,6 +70,16 @@ class Context:
         """int32 tensor view of n uint32 values that the context owns (grid arrays)."""
         if n == 0:
             return self.torch.empty(0, dtype=self.torch.int32, device=self.device)
+        key = (int(ptr), int(n))
+        cache = self.__dict__.setdefault("_wrap_cache", {})
+        if key in cache:
+            return cache[key]
+        if len(cache) > 64:
+            cache.clear()
+        cache[key] = self._wrap_u32_uncached(ptr, n)
+        return cache[key]
+
+    def _wrap_u32_uncached(self, ptr, n):
         iface = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
         holder = type("_P", (), {"__cuda_array_interface__": iface})()
         return self.torch.as_tensor(holder, device=self.device)
@@ -93,8 +106,13 @@ class Context:
         check(lib.ugrt_grid_get_info(self._h, which, C.byref(gi)))
         return gi
 
+    def grid_ptrs(self, which):
+        """(value, span, offset) as raw device pointers + the GridInfo: what a frame loop passes on."""
+        gi = self.grid_info(which)
+        return gi.d_triangle_value_list, gi.d_span, gi.d_offset, gi
+
     def grid_arrays(self, which):
-        """(value, key, span, offset) as int32 torch views + the GridInfo."""
+        """(value, key, span, offset) as int32 torch views + the GridInfo (tests, analysis)."""
         gi = self.grid_info(which)
         return (self.wrap_u32(gi.d_triangle_value_list, gi.total_refs),
                 self.wrap_u32(gi.d_triangle_key_list, gi.total_refs),

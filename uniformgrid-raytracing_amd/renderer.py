@@ -102,7 +102,7 @@ class Renderer:
         ctx.upload_camera(cam.camcoords)
         # build_frustum_grid
         ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
-        value, _, span, offset, _ = ctx.grid_arrays(GRID_PERSPECTIVE)
+        value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
         # FrustumTracer::trace
         ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed, self.intersect_id,
                           self.d_verts, self.d_faces)
@@ -111,7 +111,7 @@ class Renderer:
             ctx.upload_camera(lcam.camcoords)
             ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
             ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
-            lvalue, _, lspan, loffset, _ = ctx.grid_arrays(GRID_SPHERICAL)
+            lvalue, lspan, loffset, _ = ctx.grid_ptrs(GRID_SPHERICAL)
             self.num_chunks = ctx.sort_rays(self.d_map, self.prefix)
             ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
                              self.d_map, self.prefix, self.cam_pos, self.num_chunks)
@@ -123,7 +123,7 @@ class Renderer:
                              self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays,
                              self.active)
             ctx.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
-            uvalue, _, uspan, uoffset, _ = ctx.grid_arrays(GRID_UNIFORM)
+            uvalue, uspan, uoffset, _ = ctx.grid_ptrs(GRID_UNIFORM)
             ctx.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active, self.hit_t,
                           self.hit_id)
             ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,

@@ -68,7 +68,10 @@ def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
     cells = r.d_map[n:2 * n][heads].long()
     C_l = lgi.num_cells
     sp = torch.where(cells < C_l, lspan[cells.clamp(max=C_l - 1)].long(), torch.zeros_like(cells))
-    out["trace_shadow"] = 24 * n + 8 * nch + 52 * int(sp.sum().item())
+    # the shadow stage (24 N + sum_chunks(8 + 52 span)) runs as two kernels: the cull pass
+    # streams every (chunk, triangle) reference, the exact pass rebuilds the N rays and tests P candidates
+    out["shadow_cull"] = 8 * nch + 52 * int(sp.sum().item())
+    out["trace_shadow"] = 24 * n + 52 * int(ctx.stats()[7])
     tests, cells_visited, active = dda_counts
     out["trace_dda"] = 48 * active + 8 * cells_visited + 52 * tests
     out["_R_perspective"], out["_R_spherical"] = gi.total_refs, lgi.total_refs
@@ -224,7 +227,8 @@ def main():
     stages = {k: dict(ms_per_launch=v[0] / v[1], launches_per_step=v[1] / float(args.steps),
                       ms_per_step=v[0] / args.steps) for k, v in prof.items() if v[1]}
     gpu_ms = sum(v["ms_per_step"] for v in stages.values())
-    dom = max(("trace_primary", "trace_shadow", "trace_dda"), key=lambda k: stages.get(k, {}).get("ms_per_step", 0))
+    dom = max(("trace_primary", "shadow_cull", "trace_shadow", "trace_dda"),
+              key=lambda k: stages.get(k, {}).get("ms_per_step", 0))
     dom_ms = stages[dom]["ms_per_launch"]
     achieved = abytes[dom] / (dom_ms * 1e-3) / 1e9
     traffic = None
@@ -237,7 +241,7 @@ def main():
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel={"trace_primary": "k_trace_primary", "trace_shadow": "k_trace_shadow",
-                                         "trace_dda": "k_trace_dda"}[dom],
+                                         "shadow_cull": "k_shadow_cull", "trace_dda": "k_trace_dda"}[dom],
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                     traffic=traffic, algorithmic_bytes_per_launch=int(abytes[dom]), ms_per_launch=round(dom_ms, 4))
 

@@ -67,12 +67,13 @@ enum {
 	UGRT_ST_TRACE_PRIMARY,   /* rckernel_alpha */
 	UGRT_ST_MAP_RAYS,        /* mapSort_Effective_kernel */
 	UGRT_ST_SORT_RAYS,       /* processData */
-	UGRT_ST_TRACE_SHADOW,    /* mod_light_rckernel */
+	UGRT_ST_TRACE_SHADOW,    /* mod_light_rckernel: the exact per-ray pass */
 	UGRT_ST_SHADE,           /* lambertian_shade / spot_shade / shadow_kernel */
 	UGRT_ST_REFLECT_GEN,     /* secondary ray generation (not in reference) */
 	UGRT_ST_TRACE_DDA,       /* 3D-DDA traversal (not in reference) */
 	UGRT_ST_ANIMATE,         /* copy_data_transform */
 	UGRT_ST_WORKLIST,        /* work-item list construction for the tracers */
+	UGRT_ST_SHADOW_CULL,     /* shadow tracer's (beam, triangle) cull pass */
 	UGRT_ST_COUNT
 };
 
@@ -239,8 +240,9 @@ int ugrt_prof_reset(ugrt_ctx *ctx);
 /* total milliseconds and number of timed launches of a stage since the reset
  * (synchronises the stream) */
 int ugrt_prof_get(ugrt_ctx *ctx, int stage, double *ms_total, int *launches);
-/* counters of the last tracer launches: [0] primary work-item capacity, [1] shadow work
- * items, [2] shadow chunks traced; with UGRT_FLAG_COUNT_WORK also [3] DDA candidates tested,
+/* counters of the last tracer launches: [0] primary work-item capacity, [1] shadow beams
+ * (64-ray groups), [2] shadow chunks traced, [7] shadow (beam, triangle) candidate pairs that
+ * reached the per-ray test; with UGRT_FLAG_COUNT_WORK also [3] DDA candidates tested,
  * [4] DDA cells visited, [5] DDA active rays */
 int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8]);
 

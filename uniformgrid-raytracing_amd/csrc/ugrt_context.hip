@@ -88,7 +88,7 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 	ctx->cam.nby = nby;
 	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 16 * sizeof(u32), hipHostMallocDefault);
 	if (e == hipSuccess)
-		e = hipMalloc((void **)&ctx->d_small, (16 + 100) * sizeof(u32));
+		e = hipMalloc((void **)&ctx->d_small, (32 + 100) * sizeof(u32));
 	if (e != hipSuccess) {
 		ugrt_ctx_destroy(ctx);
 		return ugrt_fail(UGRT_EHIP, "ctx_create: %s", hipGetErrorString(e));
@@ -149,6 +149,13 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->send);
 	buf_free(ctx->scnt);
 	buf_free(ctx->sbase);
+	buf_free(ctx->tkey[0]);
+	buf_free(ctx->tkey[1]);
+	buf_free(ctx->tval[0]);
+	buf_free(ctx->tval[1]);
+	buf_free(ctx->tbcnt);
+	buf_free(ctx->tbincl);
+	buf_free(ctx->tsph);
 	if (ctx->h_pinned)
 		(void)hipHostFree(ctx->h_pinned);
 	if (ctx->d_small)
@@ -194,7 +201,7 @@ __global__ void k_store_table(TexArg t, float *dst)
 		dst[i] = t.v[i];
 }
 
-float *ugrt_ctx_tex(ugrt_ctx *ctx) { return (float *)(ctx->d_small + 16); }
+float *ugrt_ctx_tex(ugrt_ctx *ctx) { return (float *)(ctx->d_small + 32); }
 
 // per_frame_funcs.h:18-43 fillCoordinatesData (+ setDirectionTexture :161)
 extern "C" int ugrt_upload_camera(ugrt_ctx *ctx, const float camcoords[64])

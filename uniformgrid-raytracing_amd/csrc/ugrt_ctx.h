@@ -59,12 +59,14 @@ struct ugrt_ctx {
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)
 	DevBuf rspan, roffset, rstart, cchunks, cbase; // ray runs per light cell
 	DevBuf skey[2], sval[2], sdesc, sstart, send, scnt, sbase; // shadow tracer's private ray re-grouping
+	DevBuf tkey[2], tval[2], tbcnt, tbincl, tsph;              // ... and triangle re-ordering + batch spheres
 	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
 	u32 *d_small = nullptr;       // 16 u32 of device scratch (totals)
 	bool prof_on = false;
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;
 	unsigned long long stats[8] = { 0 };
+	unsigned long long shadow_stats[5] = { 0 }; // COUNT_WORK: items, spheres tested, batches loaded, survivors, rounds
 };
 
 #define UGRT_HIP(call)                                                                            \

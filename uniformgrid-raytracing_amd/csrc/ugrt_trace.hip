@@ -17,7 +17,6 @@
 #include "ugrt_dev.h"
 
 #define SEG 256u          // triangles per primary work item
-#define SSEG 1024u        // triangles per shadow work item (ray set-up is amortised over 16 batches)
 #define TRI_STRIDE 12     // floats per staged triangle (9 used, 48 B: ds_read_b128 x3)
 #define WL_THREADS 256
 
@@ -444,17 +443,27 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 // ---------------------------------------------------------------------------
 // Which sorted rays the reference traces: chunks [0, traced) = sorted rays [0, M) with
 // M = prefix[traced] (or n when every chunk is traced).  Inside that set the grouping of rays is
-// free: each ray's flag only depends on its own light cell's triangle list.  The reference's
-// chunks are 64 consecutive rays in PIXEL order inside a cell, i.e. spread over the whole cell;
-// here the traced rays of a cell are re-grouped by a Morton code of their direction from the
-// light, so that a wave's 64 rays form a narrow beam and the packet cull removes almost every
-// triangle of the cell's list before any per-ray test.  d_map / prefix (the reference-visible
-// arrays) are not modified.
-struct SItem {
-	u32 ray_start; // into the re-grouped ray list
-	u32 ray_count; // <= 64
-	u32 tri_begin; // into the light grid's value list
-	u32 tri_count; // <= SSEG
+// free, and so is the order in which a ray meets its cell's triangles: a ray's flag is 1 iff ANY
+// triangle of its light cell passes the occlusion test (light_kernel.cu:186-203).  The reference
+// gives a block 64 consecutive rays in PIXEL order (spread over the whole cell) and re-stages the
+// cell's whole list for every such chunk.  Here, privately to this tracer (d_map / prefix / the
+// light grid's arrays are not modified):
+//   1. the traced rays of a cell are re-grouped by a Morton code of their direction from the
+//      light: a group of 64 rays is a narrow beam, summarised by its direction box (32 B);
+//   2. CULL pass, lane = triangle: a wave keeps 64 triangles of a cell in registers (with the
+//      ray-independent halves of the interval test) and streams the cell's beam boxes past them;
+//      the (beam, triangle) pairs that cannot be ruled out are appended to a list.  Triangles are
+//      read once per cell instead of once per chunk;
+//   3. the pair list is sorted by beam (rocPRIM), and
+//   4. EXACT pass, lane = ray: each beam runs the reference's per-ray test on its own short list.
+// The cull is conservative with margins far above fp32 rounding, so the flags do not change.
+#define GCHUNK 256u // beams a cull work item streams past its 64 triangles
+
+struct GBox { // one beam (<= 64 re-grouped rays of one light cell)
+	float cx, cy, cz; // centre of the direction box
+	float rx, ry, rz; // half widths (slightly widened)
+	u32 ray_start;    // into the re-grouped ray list
+	u32 ray_count;
 };
 
 __device__ __forceinline__ u32 d_spread10(u32 v)
@@ -467,12 +476,24 @@ __device__ __forceinline__ u32 d_spread10(u32 v)
 	return v;
 }
 
+__device__ __forceinline__ u32 d_dir_morton(const float *unit)
+{
+	u32 q[3];
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		float f = (unit[k] * 0.5f + 0.5f) * 1023.0f;
+		f = f > 0.0f ? f : 0.0f; // also drops NaN
+		q[k] = f < 1023.0f ? (u32)f : 1023u;
+	}
+	return d_spread10(q[0]) | (d_spread10(q[1]) << 1) | (d_spread10(q[2]) << 2);
+}
+
 __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const float *__restrict__ t_value_list,
 							     const float *__restrict__ ray_direction_list,
 							     const u32 *__restrict__ d_map, const u32 *__restrict__ prefix,
 							     u32 nchunks, u32 traced, u32 n, u32 C,
-							     const float *__restrict__ cmPt, u64 *__restrict__ keys,
-							     u32 *__restrict__ vals)
+							     const u32 *__restrict__ span, const float *__restrict__ cmPt,
+							     u64 *__restrict__ keys, u32 *__restrict__ vals)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (i >= n)
@@ -483,8 +504,8 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 	u32 code = 0;
 	if (i >= M) {
 		cell = C + 1; // not traced by the reference's launch
-	} else if (cell >= C) {
-		cell = C; // sentinel cell: no triangle list
+	} else if (cell >= C || span[cell] == 0) {
+		cell = C; // sentinel cell or empty list: nothing can shadow this ray
 	} else {
 		float tVal = t_value_list[pixel];
 		float rd[3];
@@ -492,14 +513,7 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 		rd[1] = (cmPt[1] + tVal * ray_direction_list[pixel * 3 + 1]) - cam.cc[1];
 		rd[2] = (cmPt[2] + tVal * ray_direction_list[pixel * 3 + 2]) - cam.cc[2];
 		D_NORMALIZE(rd);
-		u32 q[3];
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			float f = (rd[k] * 0.5f + 0.5f) * 1023.0f;
-			f = f > 0.0f ? f : 0.0f; // also drops NaN
-			q[k] = f < 1023.0f ? (u32)f : 1023u;
-		}
-		code = d_spread10(q[0]) | (d_spread10(q[1]) << 1) | (d_spread10(q[2]) << 2);
+		code = d_dir_morton(rd);
 	}
 	keys[i] = ((u64)cell << 30) | (u64)code;
 	vals[i] = pixel;
@@ -518,132 +532,304 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const u64 *__restric
 		rend[c] = i + 1;
 }
 
-// items of light cell c = (64-ray groups of c) x (SEG-triangle segments of c); cells without rays or
-// without triangles need no work at all
+// per light cell: number of beams, and number of cull items = triangle batches x beam chunks
 __global__ __launch_bounds__(WL_THREADS) void k_shadow_count(const u32 *__restrict__ span, const u32 *__restrict__ rstart,
-							      const u32 *__restrict__ rend, u32 C, u32 *__restrict__ cnt)
+							      const u32 *__restrict__ rend, u32 C, u32 *__restrict__ gcnt,
+							      u32 *__restrict__ icnt)
 {
 	u32 c = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (c >= C)
 		return;
-	u32 rays = rend[c] - rstart[c];
-	cnt[c] = ((rays + 63u) / 64u) * ((span[c] + SSEG - 1) / SSEG);
+	u32 g = (rend[c] - rstart[c] + 63u) / 64u;
+	u32 nb = (span[c] + 63u) / 64u;
+	gcnt[c] = g;
+	icnt[c] = nb * ((g + GCHUNK - 1) / GCHUNK);
 }
 
-__global__ __launch_bounds__(WL_THREADS) void k_shadow_items(const u32 *__restrict__ span, const u32 *__restrict__ offset,
-							      const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
-							      const u32 *__restrict__ incl, u32 C, SItem *__restrict__ items)
+// smallest c with incl[c] > x (incl = inclusive scan over C cells, x < incl[C-1])
+__device__ __forceinline__ u32 d_find_cell(const u32 *__restrict__ incl, u32 C, u32 x)
 {
-	const u32 total = incl[C - 1];
-	u32 it = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (it >= total)
-		return;
-	u32 lo = 0, hi = C - 1; // smallest c with incl[c] > it
+	u32 lo = 0, hi = C - 1;
 	while (lo < hi) {
 		u32 mid = (lo + hi) >> 1;
-		if (incl[mid] > it)
+		if (incl[mid] > x)
 			hi = mid;
 		else
 			lo = mid + 1;
 	}
-	const u32 c = lo;
-	const u32 nseg = (span[c] + SSEG - 1) / SSEG;
-	const u32 ngrp = (rend[c] - rstart[c] + 63u) / 64u;
-	const u32 local = it - (incl[c] - nseg * ngrp);
-	const u32 j = local / nseg, sg = local % nseg;
-	SItem w;
-	w.ray_start = rstart[c] + 64u * j;
-	u32 rleft = rend[c] - w.ray_start;
-	w.ray_count = rleft < 64u ? rleft : 64u;
-	w.tri_begin = offset[c] + sg * SSEG;
-	u32 tleft = span[c] - sg * SSEG;
-	w.tri_count = tleft < SSEG ? tleft : SSEG;
-	items[it] = w;
+	return lo;
 }
 
+// the rays of a beam, as the reference rebuilds them (light_kernel.cu:166-184)
+struct ShadowRay {
+	float rd[3];
+	float distance_b;
+	int pixel;
+};
+
+__device__ __forceinline__ ShadowRay d_shadow_ray(const CamBlock &cam, const float *__restrict__ t_value_list,
+						  const float *__restrict__ ray_direction_list, const float *cm, int pixel)
+{
+	ShadowRay r;
+	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
+	float tVal = t_value_list[pixel];
+	float pI[3];
+	pI[0] = cm[0] + tVal * ray_direction_list[pixel * 3 + 0];
+	pI[1] = cm[1] + tVal * ray_direction_list[pixel * 3 + 1];
+	pI[2] = cm[2] + tVal * ray_direction_list[pixel * 3 + 2];
+	r.rd[0] = pI[0] - lx;
+	r.rd[1] = pI[1] - ly;
+	r.rd[2] = pI[2] - lz;
+	// isSmaller's distance_b (light_kernel.cu:6) depends on the ray only
+	r.distance_b = __builtin_sqrtf((pI[0] - lx) * (pI[0] - lx) + (pI[1] - ly) * (pI[1] - ly) +
+				       (pI[2] - lz) * (pI[2] - lz));
+	D_NORMALIZE(r.rd);
+	r.pixel = pixel;
+	return r;
+}
+
+// one wave per beam: direction box of its rays
+__global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__restrict__ gincl, u32 C,
+						     const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
+						     const u32 *__restrict__ ray_pixels, const float *__restrict__ t_value_list,
+						     const float *__restrict__ ray_direction_list,
+						     const float *__restrict__ cmPt, GBox *__restrict__ boxes)
+{
+	const u32 total = gincl[C - 1];
+	const int lane = threadIdx.x;
+	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
+	for (u32 g = blockIdx.x; g < total; g += gridDim.x) {
+		const u32 c = d_find_cell(gincl, C, g);
+		const u32 ngrp = (rend[c] - rstart[c] + 63u) / 64u;
+		const u32 j = g - (gincl[c] - ngrp);
+		const u32 start = rstart[c] + 64u * j;
+		const u32 left = rend[c] - start;
+		const u32 cnt = left < 64u ? left : 64u;
+		const bool have = (u32)lane < cnt;
+		float rd[3] = { 0.0f, 0.0f, 0.0f };
+		if (have) {
+			ShadowRay r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm, (int)ray_pixels[start + lane]);
+			rd[0] = r.rd[0];
+			rd[1] = r.rd[1];
+			rd[2] = r.rd[2];
+		}
+		const DirBox bx = d_dir_box(rd, have);
+		if (lane == 0) {
+			GBox o;
+			o.cx = 0.5f * (bx.lo[0] + bx.hi[0]);
+			o.cy = 0.5f * (bx.lo[1] + bx.hi[1]);
+			o.cz = 0.5f * (bx.lo[2] + bx.hi[2]);
+			// half widths, widened by far more than the rounding of centre and width
+			o.rx = 0.5f * (bx.hi[0] - bx.lo[0]) + 1e-6f;
+			o.ry = 0.5f * (bx.hi[1] - bx.lo[1]) + 1e-6f;
+			o.rz = 0.5f * (bx.hi[2] - bx.lo[2]) + 1e-6f;
+			o.ray_start = start;
+			o.ray_count = cnt;
+			boxes[g] = o;
+		}
+	}
+}
+
+#define PAIR_BUF 512u
+
+__device__ __forceinline__ void d_flush_pairs(const u32 *buf_beam, const u32 *buf_tri, u32 nbuf, int lane,
+					      u32 *__restrict__ pair_count, u32 pair_cap, u32 *__restrict__ pair_beam,
+					      u32 *__restrict__ pair_tri)
+{
+	__syncthreads(); // single-wave block: orders the LDS writes before the reads below
+	u32 base = 0;
+	if (lane == 0)
+		base = atomicAdd(pair_count, nbuf);
+	base = __shfl(base, 0);
+	for (u32 i = (u32)lane; i < nbuf; i += 64u)
+		if (base + i < pair_cap) {
+			pair_beam[base + i] = buf_beam[i];
+			pair_tri[base + i] = buf_tri[i];
+		}
+	__syncthreads();
+}
+
+// CULL pass.  item -> (cell, batch of 64 triangles, chunk of GCHUNK beams).  Same test as d_cull
+// with the box as centre +- half width: f(d) = n.d ranges over n.c -+ sum_k |n_k| r_k.
 template <bool REC>
-__global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const SItem *__restrict__ items,
-						      const u32 *__restrict__ nitems_p,
-						      const u32 *__restrict__ curflist, const float *__restrict__ verts,
-						      const int *__restrict__ tris, const float4 *__restrict__ rec,
-						      const float *__restrict__ t_value_list,
+__global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__restrict__ iincl, const u32 *__restrict__ gincl,
+						    u32 C, const u32 *__restrict__ span, const u32 *__restrict__ offset,
+						    const u32 *__restrict__ value_list, const float4 *__restrict__ rec,
+						    const float *__restrict__ verts, const int *__restrict__ tris,
+						    const GBox *__restrict__ boxes, u32 *__restrict__ pair_count, u32 pair_cap,
+						    u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri)
+{
+	// candidate pairs are staged in LDS and flushed PAIR_BUF at a time: one atomic on the shared
+	// output cursor per ~450 pairs instead of one per beam iteration
+	__shared__ u32 buf_beam[PAIR_BUF], buf_tri[PAIR_BUF];
+	u32 nbuf = 0; // wave-uniform
+	const u32 total = iincl[C - 1];
+	const int lane = threadIdx.x;
+	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
+	for (u32 it = blockIdx.x; it < total; it += gridDim.x) {
+		const u32 c = d_find_cell(iincl, C, it);
+		const u32 sp = span[c];
+		const u32 nb = (sp + 63u) / 64u;
+		const u32 ngrp = gincl[c] - (c ? gincl[c - 1] : 0u);
+		const u32 gbase = gincl[c] - ngrp;
+		const u32 nq = (ngrp + GCHUNK - 1) / GCHUNK;
+		const u32 local = it - (iincl[c] - nb * nq);
+		const u32 j = local / nq, q = local % nq;
+		const u32 first = 64u * j;
+		const u32 cnt = (sp - first) < 64u ? (sp - first) : 64u;
+		const bool have = (u32)lane < cnt;
+		u32 face = 0;
+		float nA[3] = { 0, 0, 0 }, nB[3] = { 0, 0, 0 }, nD[3] = { 0, 0, 0 }, nC[3] = { 0, 0, 0 };
+		float mA = 0.0f, mB = 0.0f, mD = 0.0f;
+		if (have) {
+			face = value_list[offset[c] + first + lane];
+			float t9[9];
+			d_load_triangle<REC>(rec, verts, tris, face, lx, ly, lz, t9);
+			const float *tv = &t9[0], *e1 = &t9[3], *e2 = &t9[6];
+			D_CROSS(nA, e2, tv);
+			D_CROSS(nB, tv, e1);
+			D_CROSS(nD, e2, e1);
+#pragma unroll
+			for (int k = 0; k < 3; k++)
+				nC[k] = nA[k] + nB[k] - nD[k];
+			const float a = fmaxf(fmaxf(fabsf(tv[0]), fabsf(tv[1])), fabsf(tv[2]));
+			const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
+			const float cc = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
+			const float K = 6.0f / 65536.0f;
+			mA = fmaxf(K * a * cc, 1e-25f);
+			mB = fmaxf(K * a * b, 1e-25f);
+			mD = fmaxf(K * b * cc, 1e-25f);
+		}
+		const float mC = mA + mB + mD;
+		const u32 g0 = q * GCHUNK;
+		const u32 g1 = (g0 + GCHUNK) < ngrp ? (g0 + GCHUNK) : ngrp;
+		for (u32 g = g0; g < g1; g++) {
+			const GBox bx = boxes[gbase + g]; // wave-uniform address
+			bool keep = false;
+			if (have) {
+				const float Dm = nD[0] * bx.cx + nD[1] * bx.cy + nD[2] * bx.cz;
+				const float Dr = fabsf(nD[0]) * bx.rx + fabsf(nD[1]) * bx.ry + fabsf(nD[2]) * bx.rz;
+				const float Am = nA[0] * bx.cx + nA[1] * bx.cy + nA[2] * bx.cz;
+				const float Ar = fabsf(nA[0]) * bx.rx + fabsf(nA[1]) * bx.ry + fabsf(nA[2]) * bx.rz;
+				const float Bm = nB[0] * bx.cx + nB[1] * bx.cy + nB[2] * bx.cz;
+				const float Br = fabsf(nB[0]) * bx.rx + fabsf(nB[1]) * bx.ry + fabsf(nB[2]) * bx.rz;
+				const float Cm = nC[0] * bx.cx + nC[1] * bx.cy + nC[2] * bx.cz;
+				const float Cr = fabsf(nC[0]) * bx.rx + fabsf(nC[1]) * bx.ry + fabsf(nC[2]) * bx.rz;
+				bool cull = false;
+				if (Dm + Dr < 1e15f && Dm - Dr > -1e15f) {
+					if (Dm - Dr > mD) // det > 0 for every ray of the beam
+						cull = (Am + Ar < -mA) || (Bm + Br < -mB) || (Cm - Cr > mC);
+					else if (Dm + Dr < -mD) // det < 0
+						cull = (Am - Ar > mA) || (Bm - Br > mB) || (Cm + Cr < -mC);
+				}
+				keep = !cull;
+			}
+			const unsigned long long mask = __ballot(keep);
+			if (mask != 0ull) {
+				if (keep) {
+					const u32 pos = nbuf + d_rank_in_mask(mask);
+					buf_beam[pos] = gbase + g;
+					buf_tri[pos] = face;
+				}
+				nbuf += (u32)__popcll(mask);
+				if (nbuf > PAIR_BUF - 64u) {
+					d_flush_pairs(buf_beam, buf_tri, nbuf, lane, pair_count, pair_cap, pair_beam, pair_tri);
+					nbuf = 0;
+				}
+			}
+		}
+	}
+	if (nbuf)
+		d_flush_pairs(buf_beam, buf_tri, nbuf, lane, pair_count, pair_cap, pair_beam, pair_tri);
+}
+
+__global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict__ beam, u32 P, u32 *__restrict__ pstart,
+							   u32 *__restrict__ pend)
+{
+	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (i >= P)
+		return;
+	u32 b = beam[i];
+	if (i == 0 || beam[i - 1] != b)
+		pstart[b] = i;
+	if (i == P - 1 || beam[i + 1] != b)
+		pend[b] = i + 1;
+}
+
+#define XSEG 256u // candidates per exact-pass work item
+
+__global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
+								 u32 G, u32 *__restrict__ xcnt)
+{
+	u32 g = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (g < G)
+		xcnt[g] = (pend[g] - pstart[g] + XSEG - 1) / XSEG;
+}
+
+// EXACT pass: item -> (beam, segment of its candidate list); lane = ray, the reference's test
+template <bool REC>
+__global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__restrict__ xincl, u32 G,
+						      const GBox *__restrict__ boxes, const u32 *__restrict__ pstart,
+						      const u32 *__restrict__ pend, const u32 *__restrict__ pair_tri,
+						      const float *__restrict__ verts, const int *__restrict__ tris,
+						      const float4 *__restrict__ rec, const float *__restrict__ t_value_list,
 						      const float *__restrict__ ray_direction_list,
 						      int *__restrict__ is_shadowed, const u32 *__restrict__ ray_pixels,
 						      const float *__restrict__ cmPt)
 {
-	__shared__ __attribute__((aligned(16))) float lds[SURV_CAP * TRI_STRIDE];
+	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
 	const int lane = threadIdx.x;
-	const u32 nitems = *nitems_p;
+	const u32 total = xincl[G - 1];
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
-	const float cx = cmPt[0], cy = cmPt[1], cz = cmPt[2];
-	for (u32 it = blockIdx.x; it < nitems; it += gridDim.x) {
-		const SItem w = items[it];
-		const bool have_ray = (u32)lane < w.ray_count;
-		int pseudoPixelId = 0;
-		float rd[3] = { 0.0f, 0.0f, 1.0f }, distance_b = 0.0f;
+	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
+	for (u32 it = blockIdx.x; it < total; it += gridDim.x) {
+		const u32 g = d_find_cell(xincl, G, it);
+		const u32 nseg = (pend[g] - pstart[g] + XSEG - 1) / XSEG;
+		const u32 sgm = it - (xincl[g] - nseg);
+		const u32 p0 = pstart[g] + sgm * XSEG;
+		const u32 p1 = (p0 + XSEG) < pend[g] ? (p0 + XSEG) : pend[g];
+		const GBox bx = boxes[g];
+		const bool have_ray = (u32)lane < bx.ray_count;
+		ShadowRay r;
+		r.rd[0] = r.rd[1] = r.rd[2] = 0.0f;
+		r.distance_b = 0.0f;
+		r.pixel = 0;
 		bool done = true; // rayDoneMap == 2
 		if (have_ray) {
-			// light_kernel.cu:166-184
-			pseudoPixelId = (int)ray_pixels[w.ray_start + lane];
-			float tVal = t_value_list[pseudoPixelId];
-			float pI[3];
-			pI[0] = cx + tVal * ray_direction_list[pseudoPixelId * 3 + 0];
-			pI[1] = cy + tVal * ray_direction_list[pseudoPixelId * 3 + 1];
-			pI[2] = cz + tVal * ray_direction_list[pseudoPixelId * 3 + 2];
-			rd[0] = pI[0] - lx;
-			rd[1] = pI[1] - ly;
-			rd[2] = pI[2] - lz;
-			// isSmaller's distance_b (light_kernel.cu:6) depends on the ray only
-			distance_b = __builtin_sqrtf((pI[0] - lx) * (pI[0] - lx) + (pI[1] - ly) * (pI[1] - ly) +
-						     (pI[2] - lz) * (pI[2] - lz));
-			D_NORMALIZE(rd);
-			// a ray already flagged by another segment of its cell needs no more tests
-			done = is_shadowed[pseudoPixelId] == 1;
+			r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm, (int)ray_pixels[bx.ray_start + lane]);
+			// a ray already flagged by another segment of its beam needs no more tests
+			done = is_shadowed[r.pixel] == 1;
 		}
-		const bool active = have_ray && !done;
-		if (__ballot(active) == 0ull)
+		if (__ballot(!done) == 0ull)
 			continue;
-		const DirBox box = d_dir_box(rd, active);
 		bool hit = false;
-		u32 nsurv = 0;
-		for (u32 b = 0; b < w.tri_count || nsurv; b += 64) {
-			if (b < w.tri_count) {
-				const u32 cnt = (w.tri_count - b) < 64u ? (w.tri_count - b) : 64u;
-				bool keep = false;
+		for (u32 b = p0; b < p1; b += 64) {
+			const u32 cnt = (p1 - b) < 64u ? (p1 - b) : 64u;
+			__syncthreads();
+			if ((u32)lane < cnt) {
 				float t9[9];
-				if ((u32)lane < cnt) {
-					d_load_triangle<REC>(rec, verts, tris, curflist[w.tri_begin + b + lane], lx, ly, lz, t9);
-					keep = !d_cull(&t9[0], &t9[3], &t9[6], box);
-				}
-				const unsigned long long mask = __ballot(keep);
-				if (keep) {
-					float4 *dst = reinterpret_cast<float4 *>(&lds[(nsurv + d_rank_in_mask(mask)) * TRI_STRIDE]);
-					dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
-					dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
-					dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
-				}
-				nsurv += (u32)__popcll(mask);
-				if (nsurv < 64u && b + 64 < w.tri_count)
-					continue;
+				d_load_triangle<REC>(rec, verts, tris, pair_tri[b + lane], lx, ly, lz, t9);
+				float4 *dst = reinterpret_cast<float4 *>(&lds[lane * TRI_STRIDE]);
+				dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
+				dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
+				dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
 			}
 			__syncthreads();
 			if (!done) {
-				for (u32 k = 0; k < nsurv; k++) {
+				for (u32 k = 0; k < cnt; k++) {
 					const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
 					const float4 a = src[0], c = src[1], e = src[2];
-					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y },
-						    e2[3] = { c.z, c.w, e.x };
-					const float value = d_intersect_tri(tv, e1, e2, rd, 999999.9f);
+					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
+					const float value = d_intersect_tri(tv, e1, e2, r.rd, 999999.9f);
 					if (value != 0.0f) {
 						// light_kernel.cu:193-202 with isSmaller (:1-11)
 						float pt[3];
-						pt[0] = lx + value * rd[0];
-						pt[1] = ly + value * rd[1];
-						pt[2] = lz + value * rd[2];
-						float distance_a =
-							__builtin_sqrtf((pt[0] - lx) * (pt[0] - lx) + (pt[1] - ly) * (pt[1] - ly) +
-									(pt[2] - lz) * (pt[2] - lz));
-						if (distance_a + 1e-03f < distance_b) {
+						pt[0] = lx + value * r.rd[0];
+						pt[1] = ly + value * r.rd[1];
+						pt[2] = lz + value * r.rd[2];
+						float distance_a = __builtin_sqrtf((pt[0] - lx) * (pt[0] - lx) + (pt[1] - ly) * (pt[1] - ly) +
+										   (pt[2] - lz) * (pt[2] - lz));
+						if (distance_a + 1e-03f < r.distance_b) {
 							hit = true;
 							done = true;
 							break;
@@ -651,14 +837,12 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const SItem *
 					}
 				}
 			}
-			__syncthreads();
-			nsurv = 0;
-			// the whole beam is decided: skip the remaining triangle batches
+			// the whole beam is decided: skip the remaining candidates
 			if (__ballot(!done) == 0ull)
 				break;
 		}
 		if (hit)
-			is_shadowed[pseudoPixelId] = 1;
+			is_shadowed[r.pixel] = 1;
 	}
 }
 
@@ -696,8 +880,11 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	}
 	ctx->stats[2] = traced;
 	ctx->stats[1] = 0;
+	ctx->stats[6] = ctx->stats[7] = 0;
 	if (traced == 0 || n == 0)
 		return UGRT_OK;
+	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
+	const float4 *rec = use_rec ? (const float4 *)ctx->trirec.p : (const float4 *)nullptr;
 	int rc;
 	for (int i = 0; i < 2; i++) {
 		if ((rc = ugrt_buf_reserve(ctx, ctx->skey[i], (size_t)n * 8)))
@@ -706,21 +893,34 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			return rc;
 	}
 	const u32 ncellk = C + 2; // + sentinel + "not traced"
+	const size_t maxg = (size_t)n / 64 + C + 1; // beams
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sstart, (size_t)ncellk * 4)))
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->send, (size_t)ncellk * 4)))
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->scnt, (size_t)C * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->scnt, (size_t)C * 8)))
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->sbase, (size_t)C * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sbase, (size_t)C * 8)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sdesc, maxg * sizeof(GBox))))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->tbcnt, maxg * 4)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->tbincl, maxg * 4)))
+		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, maxg * 8)))
 		return rc;
 	u64 *k0 = (u64 *)ctx->skey[0].p, *k1 = (u64 *)ctx->skey[1].p;
 	u32 *v0 = (u32 *)ctx->sval[0].p, *v1 = (u32 *)ctx->sval[1].p;
-	u32 *rstart = (u32 *)ctx->sstart.p, *rend = (u32 *)ctx->send.p, *cnt = (u32 *)ctx->scnt.p,
-	    *incl = (u32 *)ctx->sbase.p;
+	u32 *rstart = (u32 *)ctx->sstart.p, *rend = (u32 *)ctx->send.p;
+	u32 *gcnt = (u32 *)ctx->scnt.p, *icnt = gcnt + C, *gincl = (u32 *)ctx->sbase.p, *iincl = gincl + C;
+	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = (u32 *)ctx->tbincl.p;
+	GBox *boxes = (GBox *)ctx->sdesc.p;
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
+	// 1. rays: (cell, direction code) order, runs per cell, beams
 	hipLaunchKernelGGL(k_shadow_keys, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, ctx->cam,
-			   d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_cam_position, k0, v0);
+			   d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span, d_cam_position, k0,
+			   v0);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_sort_pairs64(ctx, k0, k1, v0, v1, n, 30 + bits_of(ncellk))))
 		return rc;
@@ -730,37 +930,97 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			   (const u64 *)k1, n, rstart, rend);
 	UGRT_HIP(hipGetLastError());
 	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
-			   (const u32 *)rstart, (const u32 *)rend, C, cnt);
+			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt);
 	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_inclusive_scan(ctx, cnt, incl, C)))
+	if ((rc = ugrt_prim_inclusive_scan(ctx, gcnt, gincl, C)))
 		return rc;
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, incl + (C - 1), 4, hipMemcpyDeviceToHost, st));
-	UGRT_HIP(hipStreamSynchronize(st));
-	const u32 nitems = ctx->h_pinned[10];
-	ctx->stats[1] = nitems;
-	if (nitems == 0) {
-		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
-		return UGRT_OK;
-	}
-	if ((rc = ugrt_buf_reserve(ctx, ctx->sdesc, (size_t)nitems * sizeof(SItem))))
+	if ((rc = ugrt_prim_inclusive_scan(ctx, icnt, iincl, C)))
 		return rc;
-	SItem *items = (SItem *)ctx->sdesc.p;
-	hipLaunchKernelGGL(k_shadow_items, dim3((nitems + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
-			   d_offset, (const u32 *)rstart, (const u32 *)rend, (const u32 *)incl, C, items);
+	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64), 0, st, ctx->cam,
+			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
+			   d_ray_dir, d_cam_position, boxes);
+	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+	// 2. cull pass -> (beam, triangle) candidate pairs; grows the pair buffer and repeats if it was too small
+	u32 *pcount = ctx->d_small + 1;
+	u32 P = 0;
+	for (int attempt = 0; attempt < 3; attempt++) {
+		size_t cap = ctx->tkey[0].cap / 4;
+		if (cap < (size_t)1 << 22) {
+			if ((rc = ugrt_buf_reserve(ctx, ctx->tkey[0], (size_t)4 << 22)) ||
+			    (rc = ugrt_buf_reserve(ctx, ctx->tkey[1], (size_t)4 << 22)) ||
+			    (rc = ugrt_buf_reserve(ctx, ctx->tval[0], (size_t)4 << 22)) ||
+			    (rc = ugrt_buf_reserve(ctx, ctx->tval[1], (size_t)4 << 22)))
+				return rc;
+		}
+		cap = ctx->tkey[0].cap / 4;
+		if (ctx->tkey[1].cap / 4 < cap)
+			cap = ctx->tkey[1].cap / 4;
+		if (ctx->tval[0].cap / 4 < cap)
+			cap = ctx->tval[0].cap / 4;
+		if (ctx->tval[1].cap / 4 < cap)
+			cap = ctx->tval[1].cap / 4;
+		if (cap > 0xFFFFFFF0u)
+			cap = 0xFFFFFFF0u;
+		UGRT_HIP(hipMemsetAsync(pcount, 0, 4, st));
+		ugrt_prof_begin(ctx, UGRT_ST_SHADOW_CULL);
+		if (use_rec)
+			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
+					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
+					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p);
+		else
+			hipLaunchKernelGGL(k_shadow_cull<false>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
+					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
+					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p);
+		ugrt_prof_end(ctx, UGRT_ST_SHADOW_CULL);
+		UGRT_HIP(hipGetLastError());
+		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, pcount, 4, hipMemcpyDeviceToHost, st));
+		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 12, gincl + (C - 1), 4, hipMemcpyDeviceToHost, st));
+		UGRT_HIP(hipStreamSynchronize(st));
+		P = ctx->h_pinned[10];
+		if ((size_t)P <= cap)
+			break;
+		if (attempt == 2)
+			return ugrt_fail(UGRT_ENOMEM, "trace_shadow: %u candidate pairs do not fit", P);
+		size_t want = (size_t)P * 4 + ((size_t)P * 4) / 4;
+		if ((rc = ugrt_buf_reserve(ctx, ctx->tkey[0], want)) || (rc = ugrt_buf_reserve(ctx, ctx->tkey[1], want)) ||
+		    (rc = ugrt_buf_reserve(ctx, ctx->tval[0], want)) || (rc = ugrt_buf_reserve(ctx, ctx->tval[1], want)))
+			return rc;
+	}
+	const u32 G = ctx->h_pinned[12];
+	ctx->stats[1] = G;
+	ctx->stats[7] = P;
+	if (P == 0 || G == 0)
+		return UGRT_OK;
+	// 3. candidates by beam
+	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
+	if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
+				       (u32 *)ctx->tval[1].p, P, bits_of(G))))
+		return rc;
+	UGRT_HIP(hipMemsetAsync(pstart, 0, (size_t)G * 4, st));
+	UGRT_HIP(hipMemsetAsync(pend, 0, (size_t)G * 4, st));
+	hipLaunchKernelGGL(k_pair_runs, dim3((P + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   (const u32 *)ctx->tkey[1].p, P, pstart, pend);
 	UGRT_HIP(hipGetLastError());
-	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
+	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + G;
+	hipLaunchKernelGGL(k_pair_item_count, dim3((G + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   (const u32 *)pstart, (const u32 *)pend, G, xcnt);
+	UGRT_HIP(hipGetLastError());
+	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, G)))
+		return rc;
+	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	if (use_rec)
-		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
-				   (const SItem *)items, (const u32 *)(incl + (C - 1)), d_value_list, d_vertlist, d_trilist,
-				   (const float4 *)ctx->trirec.p, d_t_value, d_ray_dir, d_is_shadowed, (const u32 *)v1,
-				   d_cam_position);
+		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(G + P / XSEG)), dim3(64), 0, st, ctx->cam,
+				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
+				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
+				   (const u32 *)v1, d_cam_position);
 	else
-		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(nitems)), dim3(64), 0, st, ctx->cam,
-				   (const SItem *)items, (const u32 *)(incl + (C - 1)), d_value_list, d_vertlist, d_trilist,
-				   (const float4 *)nullptr, d_t_value, d_ray_dir, d_is_shadowed, (const u32 *)v1,
-				   d_cam_position);
+		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(G + P / XSEG)), dim3(64), 0, st, ctx->cam,
+				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
+				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
+				   (const u32 *)v1, d_cam_position);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

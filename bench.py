@@ -99,12 +99,15 @@ def cpu_baseline(ugrt, s, setup, W, H, lg, udims, seconds):
         return wall, tf, rays
 
     mid = nby // 2
-    w1, f1, _ = run((mid, mid + 2))
-    per_row = max((w1 - f1) / 2.0, 1e-4)
-    nrows = int(max(2, min(nby, (seconds - f1) / per_row)))
-    lo = max(0, mid - nrows // 2)
-    rows = (lo, min(nby, lo + nrows))
-    wall, tf, rays = run(rows)
+    nrows, wall, tf, rays, rows = 2, 0.0, 0.0, 0, (mid, mid + 2)
+    for _ in range(4):  # grow the band until the sample costs about `seconds` of CPU time (or is the frame)
+        lo = max(0, mid - nrows // 2)
+        rows = (lo, min(nby, lo + nrows))
+        wall, tf, rays = run(rows)
+        if wall >= 0.6 * seconds or rows[1] - rows[0] >= nby:
+            break
+        per_row = max((wall - tf) / float(rows[1] - rows[0]), 1e-4)
+        nrows = int(max(nrows + 1, min(nby, (seconds - tf) / per_row)))
     scale = nby / float(rows[1] - rows[0])
     t_full = tf + (wall - tf) * scale
     value = rays * scale / t_full / 1e6

@@ -313,3 +313,48 @@ def test_error_paths(ugrt, torch):
         ctx.grid_info(ugrt.GRID_UNIFORM)  # not built
     with pytest.raises(ugrt.UgrtError):
         ctx.grid_build_perspective(None, None, 3)
+
+
+def test_full_size_bench_workload(ugrt, O, torch):
+    """BASELINE configs[2] at full size (1M triangles, 1920x1080, primary + shadow + bounce) on the GPU;
+    the oracle checks a band of tile rows bit for bit (per-ray results do not depend on the other rays when
+    every shadow chunk is traced) and the whole frame through size-independent properties."""
+    s = ugrt.scenes.crash(scale=1.0)
+    W, H, lg, ud = 1920, 1080, (128, 128), (128, 128, 64)
+    ctx, r = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    setup = setup_for(ugrt, s, "ref")
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    N = W * H
+    # --- properties over the whole frame
+    value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
+    k = u32(key).astype(np.int64)
+    assert (np.diff(k) >= 0).all() and gi.total_refs == len(k) > 10 ** 7
+    sp, off, v = u32(span).astype(np.int64), u32(offset).astype(np.int64), u32(value).astype(np.int64)
+    assert sp.sum() == gi.total_refs and (off == np.concatenate([[0], np.cumsum(sp)[:-1]])).all()
+    same = k[1:] == k[:-1]
+    assert (v[1:][same] > v[:-1][same]).all()  # stable: ascending triangle ids inside a cell
+    np.testing.assert_array_equal(np.bincount(k, minlength=gi.num_cells), sp)
+    dm = u32(r.d_map)
+    assert (np.sort(dm[:N]) == np.arange(N)).all() and (np.diff(dm[N:].astype(np.int64)) >= 0).all()
+    pf = u32(r.prefix)[:r.num_chunks].astype(np.int64)
+    assert pf[0] == 0 and (np.diff(pf) > 0).all() and (np.diff(pf) <= 64).all()
+    t = r.t.cpu().numpy()
+    d = r.dir.cpu().numpy().reshape(-1, 3)
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-5)
+    hid, act = r.hit_id.cpu().numpy(), r.active.cpu().numpy()
+    assert ((hid >= 0) <= (act == 1)).all() and act.sum() > 10 ** 5
+    assert ((t > 0) | (t == -1)).all()
+    # --- the oracle on a band of 4 tile rows through the middle of the image
+    rows = (66, 70)
+    want = O.frame(s, setup, W, H, rows=rows, light_grid=lg, all_chunks=True, reflect=True, uniform_dims=ud)
+    a, b = want["p0"], want["p0"] + want["n"]
+    pr = want["primary"]
+    np.testing.assert_array_equal(t[a:b].view(np.uint32), pr["t"][a:b].view(np.uint32))
+    np.testing.assert_array_equal(r.normal.cpu().numpy()[3 * a:3 * b].view(np.uint32), pr["normal"][3 * a:3 * b].view(np.uint32))
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy()[a:b], want["is_shadowed"][a:b])
+    np.testing.assert_array_equal(act[a:b], want["active"][a:b])
+    np.testing.assert_array_equal(hid[a:b], want["hit_id"][a:b])
+    np.testing.assert_array_equal(r.hit_t.cpu().numpy()[a:b].view(np.uint32), want["hit_t"][a:b].view(np.uint32))
+    np.testing.assert_array_equal(r.image.cpu().numpy()[3 * a:3 * b], want["image"][3 * a:3 * b])
+    assert (pr["id"][a:b] >= 0).sum() > 1000 and want["is_shadowed"][a:b].sum() > 100

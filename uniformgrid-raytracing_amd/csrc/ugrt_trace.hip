@@ -1041,6 +1041,24 @@ __device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
 	return d_clampi(c, 0, g.dims[k] - 1);
 }
 
+#define DDA_COOP 24u // cells with at least this many triangles are tested by the whole wave
+
+__device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) {
+		unsigned long long o = __shfl_xor(v, m);
+		v = o < v ? o : v;
+	}
+	return v;
+}
+
+// One lane per secondary ray, Amanatides & Woo stepping.  A ray's work is a chain of dependent
+// loads (cell header -> triangle id -> record), so the kernel is bound by its LONGEST ray; cells
+// with many triangles (the debris cloud) are therefore tested by the whole wave: the owning
+// lane's ray is broadcast, 64 triangles are tested at once (lane = triangle) and the nearest
+// accepted hit is found with a 64-bit wave min on (t bits << 32 | r).  Sequentially the cell loop
+// keeps the first r with the smallest accepted t (strict <), which is exactly that minimum.
 template <bool COUNT, bool REC>
 __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restrict__ value_list,
 						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
@@ -1050,16 +1068,20 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 						    int p0, int npix, float *__restrict__ hit_t, int *__restrict__ hit_id,
 						    unsigned long long *__restrict__ counters)
 {
-	int i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= npix)
-		return;
-	const int p = p0 + i;
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const bool inb = i < npix;
+	const int p = p0 + (inb ? i : 0);
 	float res_t = -1.0f;
 	int res_id = -2;
 	u32 n_cells = 0, n_tests = 0;
-	if (active[p]) {
-		float o[3], d[3], tmax[3], tdelta[3];
-		int c[3], step[3];
+	float o[3] = { 0, 0, 0 }, d[3] = { 0, 0, 0 }, tmax[3] = { 0, 0, 0 }, tdelta[3] = { 0, 0, 0 };
+	int c[3] = { 0, 0, 0 }, step[3] = { 0, 0, 0 };
+	float best_t = 3.0e38f;
+	int best_id = -2;
+	const bool is_active = inb && active[p] != 0;
+	bool walking = false;
+	if (is_active) {
 		float tenter = 0.0f, texit = 3.0e38f;
 #pragma unroll
 		for (int k = 0; k < 3; k++) {
@@ -1086,6 +1108,7 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 			}
 		}
 		if (tenter <= texit) {
+			walking = true;
 #pragma unroll
 			for (int k = 0; k < 3; k++) {
 				float pe = o[k] + tenter * d[k];
@@ -1104,32 +1127,68 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 					tdelta[k] = 3.0e38f;
 				}
 			}
-			float best_t = 3.0e38f;
-			int best_id = -2;
-			// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
-			for (int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3; guard > 0; guard--) {
-				u32 cell = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
-				u32 sp = span[cell], off = offset[cell];
-				int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
-				float tnext = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
-				if (COUNT) {
-					n_cells++;
-					n_tests += sp;
+		}
+	}
+	// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
+	int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3;
+	while (__ballot(walking) != 0ull) {
+		u32 sp = 0, off = 0;
+		if (walking) {
+			u32 cell = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
+			sp = span[cell];
+			off = offset[cell];
+			if (COUNT) {
+				n_cells++;
+				n_tests += sp;
+			}
+		}
+		// small lists: the owning lane tests them itself, in list order
+		if (walking && sp < DDA_COOP) {
+			for (u32 r = 0; r < sp; r++) {
+				u32 f = value_list[off + r];
+				float t9[9], t;
+				d_load_triangle<REC>(rec, verts, tris, f, o[0], o[1], o[2], t9);
+				if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
+					best_t = t;
+					best_id = (int)f;
 				}
-				for (u32 r = 0; r < sp; r++) {
-					u32 f = value_list[off + r];
+			}
+		}
+		// long lists: one owner at a time, 64 triangles per round
+		unsigned long long heavy = __ballot(walking && sp >= DDA_COOP);
+		while (heavy != 0ull) {
+			const int l = (int)__builtin_ctzll(heavy);
+			heavy &= heavy - 1ull;
+			const float ox = __shfl(o[0], l), oy = __shfl(o[1], l), oz = __shfl(o[2], l);
+			const float dl[3] = { __shfl(d[0], l), __shfl(d[1], l), __shfl(d[2], l) };
+			const float bt = __shfl(best_t, l);
+			const u32 spl = (u32)__shfl((int)sp, l), offl = (u32)__shfl((int)off, l);
+			unsigned long long kbest = ~0ull;
+			for (u32 base = 0; base < spl; base += 64) {
+				const u32 r = base + (u32)lane;
+				unsigned long long key = ~0ull;
+				if (r < spl) {
 					float t9[9], t;
-					d_load_triangle<REC>(rec, verts, tris, f, o[0], o[1], o[2], t9);
-					if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
-						best_t = t;
-						best_id = (int)f;
-					}
+					d_load_triangle<REC>(rec, verts, tris, value_list[offl + r], ox, oy, oz, t9);
+					if (d_mt_core(&t9[0], &t9[3], &t9[6], dl, &t) && t > 0.0f && t < bt)
+						key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)r;
 				}
-				if (best_id >= 0 && best_t <= tnext) {
-					res_t = best_t;
-					res_id = best_id;
-					break;
-				}
+				key = d_wave_min_u64(key);
+				kbest = key < kbest ? key : kbest;
+			}
+			if (lane == l && kbest != ~0ull) {
+				best_t = __uint_as_float((u32)(kbest >> 32));
+				best_id = (int)value_list[off + (u32)(kbest & 0xFFFFFFFFull)];
+			}
+		}
+		if (walking) {
+			int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
+			float tnext = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
+			if (best_id >= 0 && best_t <= tnext) {
+				res_t = best_t;
+				res_id = best_id;
+				walking = false;
+			} else {
 				// step along ax (written out: no dynamically indexed registers)
 				bool outside;
 				if (ax == 0) {
@@ -1145,20 +1204,22 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 					outside = step[2] == 0 || c[2] < 0 || c[2] >= g.dims[2];
 					tmax[2] += tdelta[2];
 				}
-				if (outside)
-					break;
+				if (outside || --guard <= 0)
+					walking = false;
 			}
 		}
 	}
-	hit_t[p] = res_t;
-	hit_id[p] = res_id;
-	if (COUNT) {
+	if (inb) {
+		hit_t[p] = res_t;
+		hit_id[p] = res_id;
+	}
+	if (COUNT && inb) {
 		// work counters of the algorithmic-byte formula: candidates tested, cells visited, active rays
 		if (n_tests)
 			atomicAdd(&counters[0], (unsigned long long)n_tests);
 		if (n_cells)
 			atomicAdd(&counters[1], (unsigned long long)n_cells);
-		if (active[p])
+		if (is_active)
 			atomicAdd(&counters[2], 1ull);
 	}
 }

@@ -1041,7 +1041,7 @@ __device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
 	return d_clampi(c, 0, g.dims[k] - 1);
 }
 
-#define DDA_COOP 24u // cells with at least this many triangles are tested by the whole wave
+#define DDA_COOP 16u // cells with at least this many triangles are tested by the whole wave
 
 __device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long v)
 {
@@ -1144,13 +1144,25 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 		}
 		// small lists: the owning lane tests them itself, in list order
 		if (walking && sp < DDA_COOP) {
-			for (u32 r = 0; r < sp; r++) {
-				u32 f = value_list[off + r];
-				float t9[9], t;
-				d_load_triangle<REC>(rec, verts, tris, f, o[0], o[1], o[2], t9);
-				if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
-					best_t = t;
-					best_id = (int)f;
+			// four references in flight at a time: the id loads, then the record loads, are independent
+			for (u32 r = 0; r < sp; r += 4) {
+				u32 f[4];
+				float t9[4][9];
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					f[q] = (r + q < sp) ? value_list[off + r + q] : 0u;
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					if (r + q < sp)
+						d_load_triangle<REC>(rec, verts, tris, f[q], o[0], o[1], o[2], t9[q]);
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					float t;
+					if (r + q < sp && d_mt_core(&t9[q][0], &t9[q][3], &t9[q][6], d, &t) && t > 0.0f &&
+					    t < best_t) {
+						best_t = t;
+						best_id = (int)f[q];
+					}
 				}
 			}
 		}

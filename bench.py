@@ -75,7 +75,10 @@ def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
     tests, cells_visited, active = dda_counts
     out["trace_dda"] = 48 * active + 8 * cells_visited + 52 * tests
     out["_R_perspective"], out["_R_spherical"] = gi.total_refs, lgi.total_refs
-    out["_R_uniform"] = ctx.grid_info(ugrt.GRID_UNIFORM).total_refs
+    try:
+        out["_R_uniform"] = ctx.grid_info(ugrt.GRID_UNIFORM).total_refs
+    except Exception:
+        out["_R_uniform"] = 0
     out["_shadow_span_sum"], out["_chunks"] = int(sp.sum().item()), nch
     return out
 
@@ -128,6 +131,9 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--stages-json", default="", help="also write the per-stage table to this file")
+    ap.add_argument("--no-reflect", action="store_true", help="primary + shadow only (BASELINE configs[1])")
+    ap.add_argument("--animate", action="store_true",
+                    help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
 
     import numpy as np
@@ -169,8 +175,16 @@ def main():
     r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
     gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world)
 
+    reflect = not args.no_reflect
+    if args.animate:
+        r.init_orig_list(s["animated_size"], s["animated_offset"])
+    frame_no = [0]
+
     def step():
-        r.display(setup, frame_cnt=1, shadows=True, reflect=True)
+        if args.animate:  # Model::rotate_bunny(lightRotFactor), main.cu:68 + per_frame_funcs.h:15
+            r.rotate_bunny(1.81 + 0.05 * frame_no[0])
+            frame_no[0] += 1
+        r.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
         gather.gather(r.image)
 
     for _ in range(max(1, args.warmup)):
@@ -180,18 +194,20 @@ def main():
 
     # rays per frame of this rank: primary + shadow (one per pixel, misses included: misc_kernel.cu:255)
     # + secondary rays actually shot
-    active = int(r.active[ctx.p0:ctx.p0 + ctx.npix].sum().item())
+    active = int(r.active[ctx.p0:ctx.p0 + ctx.npix].sum().item()) if reflect else 0
     rays_rank = 2 * ctx.npix + active
 
     # work counters for the DDA's algorithmic bytes: a counting context, outside the timed region
     cctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags | ugrt.FLAG_COUNT_WORK,
                         uniform_dims=udims)
     cr = ugrt.Renderer(cctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
-    cr.display(setup, frame_cnt=1, shadows=True, reflect=True)
+    cr.d_verts.copy_(r.d_verts)  # same geometry as the timed renderer (matters with --animate)
+    cr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
     cctx.synchronize()
     st = cctx.stats()
-    dda_counts = (st[3], st[4], st[5])
-    assert st[5] == active, (st[5], active)
+    dda_counts = (st[3], st[4], st[5]) if reflect else (0, 0, 0)
+    if reflect and not args.animate:
+        assert st[5] == active, (st[5], active)
     del cr, cctx
     abytes = algorithmic_bytes(torch, ugrt, ctx, r, dda_counts)
 
@@ -270,9 +286,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE configs[2] stand-in: procedural '%s' scene, %d triangles, %dx%d, primary + "
-                         "shadow (1 light, all chunks traced) + 1 reflection bounce; perspective, spherical and "
-                         "uniform grids rebuilt every frame" % (s["name"], s["num_faces"], W, H)),
+            "workload": ("BASELINE configs[%d] stand-in: procedural '%s' scene, %d triangles, %dx%d, primary + "
+                         "shadow (1 light, all chunks traced)%s; all grids rebuilt every frame%s"
+                         % (4 if args.animate else (2 if reflect else 1), s["name"], s["num_faces"], W, H,
+                            " + 1 reflection bounce" if reflect else "",
+                            "; animated sub-range transformed every frame" if args.animate else "")),
+            "frames_per_s": round(args.steps / elapsed, 2),
             "rays_per_frame": int(rays_total),
             "tile": 8, "light_grid": list(lg), "uniform_grid": list(udims),
             "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",

@@ -703,8 +703,11 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 		const float mC = mA + mB + mD;
 		const u32 g0 = q * GCHUNK;
 		const u32 g1 = (g0 + GCHUNK) < ngrp ? (g0 + GCHUNK) : ngrp;
+		GBox nxt = boxes[gbase + g0]; // wave-uniform address: scalar loads
 		for (u32 g = g0; g < g1; g++) {
-			const GBox bx = boxes[gbase + g]; // wave-uniform address
+			const GBox bx = nxt;
+			// the next beam's box is requested before this one is used: its latency hides behind the test
+			nxt = boxes[gbase + ((g + 1 < g1) ? g + 1 : g)];
 			bool keep = false;
 			if (have) {
 				const float Dm = nD[0] * bx.cx + nD[1] * bx.cy + nD[2] * bx.cz;
@@ -1041,7 +1044,9 @@ __device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
 	return d_clampi(c, 0, g.dims[k] - 1);
 }
 
-#define DDA_COOP 16u // cells with at least this many triangles are tested by the whole wave
+#define DDA_COOP 8u  // cells with at least this many triangles are tested by the whole wave
+#define DDA_AHEAD 4   // cells planned (and their headers fetched) per round trip
+#define DDA_RPW 16u   // secondary rays per wave
 
 __device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long v)
 {
@@ -1059,19 +1064,49 @@ __device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long 
 // lane's ray is broadcast, 64 triangles are tested at once (lane = triangle) and the nearest
 // accepted hit is found with a 64-bit wave min on (t bits << 32 | r).  Sequentially the cell loop
 // keeps the first r with the smallest accepted t (strict <), which is exactly that minimum.
-template <bool COUNT, bool REC>
-__global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restrict__ value_list,
-						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
-						    const float *__restrict__ verts, const int *__restrict__ tris,
-						    const float4 *__restrict__ rec,
-						    const float *__restrict__ rays, const int *__restrict__ active,
-						    int p0, int npix, float *__restrict__ hit_t, int *__restrict__ hit_id,
-						    unsigned long long *__restrict__ counters)
+// default results for every pixel + the list of active secondary rays (order is irrelevant)
+__global__ __launch_bounds__(256) void k_dda_prepare(const int *__restrict__ active, int p0, int npix,
+						      float *__restrict__ hit_t, int *__restrict__ hit_id,
+						      u32 *__restrict__ list, u32 *__restrict__ count)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	const int lane = threadIdx.x & 63;
-	const bool inb = i < npix;
-	const int p = p0 + (inb ? i : 0);
+	bool a = false;
+	int p = 0;
+	if (i < npix) {
+		p = p0 + i;
+		a = active[p] != 0;
+		hit_t[p] = -1.0f;
+		hit_id[p] = -2;
+	}
+	const unsigned long long mask = __ballot(a);
+	if (mask != 0ull) {
+		u32 base = 0;
+		if ((threadIdx.x & 63) == (u32)__builtin_ctzll(mask))
+			base = atomicAdd(count, (u32)__popcll(mask));
+		base = __shfl(base, (int)__builtin_ctzll(mask));
+		if (a)
+			list[base + d_rank_in_mask(mask)] = (u32)p;
+	}
+}
+
+template <bool COUNT, bool REC>
+__global__ __launch_bounds__(64) void k_trace_dda(DGrid g, const u32 *__restrict__ value_list,
+						   const u32 *__restrict__ span, const u32 *__restrict__ offset,
+						   const float *__restrict__ verts, const int *__restrict__ tris,
+						   const float4 *__restrict__ rec,
+						   const float *__restrict__ rays, const u32 *__restrict__ list,
+						   const u32 *__restrict__ count_p, float *__restrict__ hit_t,
+						   int *__restrict__ hit_id, unsigned long long *__restrict__ counters)
+{
+	const int lane = threadIdx.x;
+	const u32 count = *count_p;
+	// DDA_RPW rays per wave: the walk of a ray is a serial chain, and the rays that cross the debris
+	// cloud carry most of the tests, so few rays per wave spreads those chains over the chip while
+	// all 64 lanes still serve the cooperative rounds
+	for (u32 grp = blockIdx.x; grp * DDA_RPW < count; grp += gridDim.x) {
+	const u32 slot = grp * DDA_RPW + (u32)lane;
+	const bool inb = (u32)lane < DDA_RPW && slot < count;
+	const int p = inb ? (int)list[slot] : 0;
 	float res_t = -1.0f;
 	int res_id = -2;
 	u32 n_cells = 0, n_tests = 0;
@@ -1079,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 	int c[3] = { 0, 0, 0 }, step[3] = { 0, 0, 0 };
 	float best_t = 3.0e38f;
 	int best_id = -2;
-	const bool is_active = inb && active[p] != 0;
+	const bool is_active = inb;
 	bool walking = false;
 	if (is_active) {
 		float tenter = 0.0f, texit = 3.0e38f;
@@ -1132,75 +1167,22 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 	// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
 	int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3;
 	while (__ballot(walking) != 0ull) {
-		u32 sp = 0, off = 0;
-		if (walking) {
-			u32 cell = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
-			sp = span[cell];
-			off = offset[cell];
-			if (COUNT) {
-				n_cells++;
-				n_tests += sp;
-			}
-		}
-		// small lists: the owning lane tests them itself, in list order
-		if (walking && sp < DDA_COOP) {
-			// four references in flight at a time: the id loads, then the record loads, are independent
-			for (u32 r = 0; r < sp; r += 4) {
-				u32 f[4];
-				float t9[4][9];
+		// The walk itself does not depend on what the cells hold, so the next DDA_AHEAD cells are
+		// planned first and their headers fetched together: one memory round trip per DDA_AHEAD steps.
+		u32 pcell[DDA_AHEAD], psp[DDA_AHEAD], poff[DDA_AHEAD];
+		float ptnext[DDA_AHEAD];
+		bool pvalid[DDA_AHEAD], pend[DDA_AHEAD];
+		bool planning = walking;
 #pragma unroll
-				for (int q = 0; q < 4; q++)
-					f[q] = (r + q < sp) ? value_list[off + r + q] : 0u;
-#pragma unroll
-				for (int q = 0; q < 4; q++)
-					if (r + q < sp)
-						d_load_triangle<REC>(rec, verts, tris, f[q], o[0], o[1], o[2], t9[q]);
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					float t;
-					if (r + q < sp && d_mt_core(&t9[q][0], &t9[q][3], &t9[q][6], d, &t) && t > 0.0f &&
-					    t < best_t) {
-						best_t = t;
-						best_id = (int)f[q];
-					}
-				}
-			}
-		}
-		// long lists: one owner at a time, 64 triangles per round
-		unsigned long long heavy = __ballot(walking && sp >= DDA_COOP);
-		while (heavy != 0ull) {
-			const int l = (int)__builtin_ctzll(heavy);
-			heavy &= heavy - 1ull;
-			const float ox = __shfl(o[0], l), oy = __shfl(o[1], l), oz = __shfl(o[2], l);
-			const float dl[3] = { __shfl(d[0], l), __shfl(d[1], l), __shfl(d[2], l) };
-			const float bt = __shfl(best_t, l);
-			const u32 spl = (u32)__shfl((int)sp, l), offl = (u32)__shfl((int)off, l);
-			unsigned long long kbest = ~0ull;
-			for (u32 base = 0; base < spl; base += 64) {
-				const u32 r = base + (u32)lane;
-				unsigned long long key = ~0ull;
-				if (r < spl) {
-					float t9[9], t;
-					d_load_triangle<REC>(rec, verts, tris, value_list[offl + r], ox, oy, oz, t9);
-					if (d_mt_core(&t9[0], &t9[3], &t9[6], dl, &t) && t > 0.0f && t < bt)
-						key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)r;
-				}
-				key = d_wave_min_u64(key);
-				kbest = key < kbest ? key : kbest;
-			}
-			if (lane == l && kbest != ~0ull) {
-				best_t = __uint_as_float((u32)(kbest >> 32));
-				best_id = (int)value_list[off + (u32)(kbest & 0xFFFFFFFFull)];
-			}
-		}
-		if (walking) {
-			int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
-			float tnext = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
-			if (best_id >= 0 && best_t <= tnext) {
-				res_t = best_t;
-				res_id = best_id;
-				walking = false;
-			} else {
+		for (int q = 0; q < DDA_AHEAD; q++) {
+			pvalid[q] = planning;
+			pend[q] = false;
+			pcell[q] = 0;
+			ptnext[q] = 0.0f;
+			if (planning) {
+				pcell[q] = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
+				int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
+				ptnext[q] = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
 				// step along ax (written out: no dynamically indexed registers)
 				bool outside;
 				if (ax == 0) {
@@ -1216,8 +1198,72 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 					outside = step[2] == 0 || c[2] < 0 || c[2] >= g.dims[2];
 					tmax[2] += tdelta[2];
 				}
-				if (outside || --guard <= 0)
+				if (outside || --guard <= 0) {
+					pend[q] = true; // the walk ends after this cell unless it ends there with a hit
+					planning = false;
+				}
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < DDA_AHEAD; q++) {
+			psp[q] = pvalid[q] ? span[pcell[q]] : 0u;
+			poff[q] = pvalid[q] ? offset[pcell[q]] : 0u;
+		}
+#pragma unroll
+		for (int q = 0; q < DDA_AHEAD; q++) {
+			const bool here = walking && pvalid[q];
+			const u32 sp = here ? psp[q] : 0u, off = poff[q];
+			if (COUNT && here) {
+				n_cells++;
+				n_tests += sp;
+			}
+			// small lists: the owning lane tests them itself, in list order
+			if (here && sp < DDA_COOP) {
+				for (u32 r = 0; r < sp; r++) {
+					u32 f = value_list[off + r];
+					float t9[9], t;
+					d_load_triangle<REC>(rec, verts, tris, f, o[0], o[1], o[2], t9);
+					if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
+						best_t = t;
+						best_id = (int)f;
+					}
+				}
+			}
+			// long lists: one owner at a time, 64 triangles per round
+			unsigned long long heavy = __ballot(here && sp >= DDA_COOP);
+			while (heavy != 0ull) {
+				const int l = (int)__builtin_ctzll(heavy);
+				heavy &= heavy - 1ull;
+				const float ox = __shfl(o[0], l), oy = __shfl(o[1], l), oz = __shfl(o[2], l);
+				const float dl[3] = { __shfl(d[0], l), __shfl(d[1], l), __shfl(d[2], l) };
+				const float bt = __shfl(best_t, l);
+				const u32 spl = (u32)__shfl((int)sp, l), offl = (u32)__shfl((int)off, l);
+				unsigned long long kbest = ~0ull;
+				for (u32 base = 0; base < spl; base += 64) {
+					const u32 r = base + (u32)lane;
+					unsigned long long key = ~0ull;
+					if (r < spl) {
+						float t9[9], t;
+						d_load_triangle<REC>(rec, verts, tris, value_list[offl + r], ox, oy, oz, t9);
+						if (d_mt_core(&t9[0], &t9[3], &t9[6], dl, &t) && t > 0.0f && t < bt)
+							key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)r;
+					}
+					key = d_wave_min_u64(key);
+					kbest = key < kbest ? key : kbest;
+				}
+				if (lane == l && kbest != ~0ull) {
+					best_t = __uint_as_float((u32)(kbest >> 32));
+					best_id = (int)value_list[off + (u32)(kbest & 0xFFFFFFFFull)];
+				}
+			}
+			if (here) {
+				if (best_id >= 0 && best_t <= ptnext[q]) {
+					res_t = best_t;
+					res_id = best_id;
 					walking = false;
+				} else if (pend[q]) {
+					walking = false;
+				}
 			}
 		}
 	}
@@ -1231,9 +1277,9 @@ __global__ __launch_bounds__(256) void k_trace_dda(DGrid g, const u32 *__restric
 			atomicAdd(&counters[0], (unsigned long long)n_tests);
 		if (n_cells)
 			atomicAdd(&counters[1], (unsigned long long)n_cells);
-		if (is_active)
-			atomicAdd(&counters[2], 1ull);
+		atomicAdd(&counters[2], 1ull);
 	}
+	} // groups
 }
 
 extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
@@ -1254,13 +1300,36 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		g.inv[k] = G.ug[6 + k];
 		g.dims[k] = G.dims[k];
 	}
-	if (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) {
+	int rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)ctx->npix * 4)))
+		return rc;
+	u32 *list = (u32 *)ctx->wscan.p, *dcount = ctx->d_small + 2;
+	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
+	const float4 *rec = use_rec ? (const float4 *)ctx->trirec.p : (const float4 *)nullptr;
+	const bool counting = (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) != 0;
+	unsigned long long *dc = (unsigned long long *)(ctx->d_small + 8);
+	if (!counting)
+		ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
+	UGRT_HIP(hipMemsetAsync(dcount, 0, 4, ctx->stream));
+	hipLaunchKernelGGL(k_dda_prepare, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, d_active, ctx->p0,
+			   ctx->npix, d_hit_t, d_hit_id, list, dcount);
+	if (!counting) {
+		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+		ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
+	}
+	UGRT_HIP(hipGetLastError());
+	const int blocks = launch_blocks_for((u32)ctx->npix / DDA_RPW + 1u);
+#define UGRT_LAUNCH_DDA(CNTV, RECV, DC)                                                                              \
+	hipLaunchKernelGGL((k_trace_dda<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
+			   d_offset, d_vertlist, d_trilist, rec, d_rays, (const u32 *)list, (const u32 *)dcount,     \
+			   d_hit_t, d_hit_id, DC)
+	if (counting) {
 		// counting variant (never the timed one): same traversal + three atomics per ray
-		unsigned long long *dc = (unsigned long long *)(ctx->d_small + 8);
 		UGRT_HIP(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), ctx->stream));
-		hipLaunchKernelGGL((k_trace_dda<true, false>), dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
-				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, (const float4 *)nullptr, d_rays,
-				   d_active, ctx->p0, ctx->npix, d_hit_t, d_hit_id, dc);
+		if (use_rec)
+			UGRT_LAUNCH_DDA(true, true, dc);
+		else
+			UGRT_LAUNCH_DDA(true, false, dc);
 		UGRT_HIP(hipGetLastError());
 		unsigned long long h[3];
 		UGRT_HIP(hipMemcpyAsync(h, dc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1270,16 +1339,11 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		ctx->stats[5] = h[2];
 		return UGRT_OK;
 	}
-	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
-	ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
 	if (use_rec)
-		hipLaunchKernelGGL((k_trace_dda<false, true>), dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
-				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, (const float4 *)ctx->trirec.p,
-				   d_rays, d_active, ctx->p0, ctx->npix, d_hit_t, d_hit_id, (unsigned long long *)nullptr);
+		UGRT_LAUNCH_DDA(false, true, (unsigned long long *)nullptr);
 	else
-		hipLaunchKernelGGL((k_trace_dda<false, false>), dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, g,
-				   d_value_list, d_span, d_offset, d_vertlist, d_trilist, (const float4 *)nullptr, d_rays,
-				   d_active, ctx->p0, ctx->npix, d_hit_t, d_hit_id, (unsigned long long *)nullptr);
+		UGRT_LAUNCH_DDA(false, false, (unsigned long long *)nullptr);
+#undef UGRT_LAUNCH_DDA
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_DDA);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

@@ -257,11 +257,9 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz)
 		if ((rc = ugrt_buf_reserve(ctx, G.val[i], rb)))
 			return rc;
 	}
-	if ((rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 8 + 16))) // span[C], run starts[C], cells_used
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.offset, (size_t)C * 4)))
-		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, G.cstart, (size_t)C * 4)))
 		return rc;
 	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
 	if (R) {
@@ -279,15 +277,14 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz)
 	G.keys = k1;
 	G.vals = v1;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
-	UGRT_HIP(hipMemsetAsync(G.span.p, 0, (size_t)C * 4, st));
-	UGRT_HIP(hipMemsetAsync(G.cstart.p, 0, (size_t)C * 4, st));
-	UGRT_HIP(hipMemsetAsync(ctx->d_small, 0, 4, st));
+	u32 *cstart = (u32 *)G.span.p + C, *used = cstart + C;
+	UGRT_HIP(hipMemsetAsync(G.span.p, 0, (size_t)C * 8 + 4, st)); // one fill for all three
 	if (R) {
 		hipLaunchKernelGGL(k_bounds, dim3((R + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)k1, R, (u32 *)G.cstart.p, (u32 *)G.span.p);
+				   (const u32 *)k1, R, cstart, (u32 *)G.span.p);
 		UGRT_HIP(hipGetLastError());
 		hipLaunchKernelGGL(k_span, dim3((C + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)G.cstart.p, (u32 *)G.span.p, C, ctx->d_small);
+				   (const u32 *)cstart, (u32 *)G.span.p, C, used);
 		UGRT_HIP(hipGetLastError());
 	}
 	rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C);
@@ -295,7 +292,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz)
 	if (rc)
 		return rc;
 	// "Number of actual cells" (frustum_grid.h:337): fetched lazily by ugrt_grid_get_info
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + (&G - ctx->grid), ctx->d_small, 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + (&G - ctx->grid), used, 4, hipMemcpyDeviceToHost, st));
 	G.valid = true;
 	return UGRT_OK;
 }

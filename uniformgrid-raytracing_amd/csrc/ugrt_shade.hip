@@ -83,18 +83,27 @@ __global__ __launch_bounds__(PX_THREADS) void k_chunk_count(const u32 *__restric
 	cchunks[c] = (rend[c] - rstart[c] + 63u) / 64u;
 }
 
+// one thread per CHUNK (a cell with thousands of rays would otherwise serialise one thread)
 __global__ __launch_bounds__(PX_THREADS) void k_chunk_emit(const u32 *__restrict__ rstart,
 							    const u32 *__restrict__ cchunks,
 							    const u32 *__restrict__ incl, u32 ncell, u32 cap,
 							    u32 *__restrict__ prefix)
 {
-	u32 c = blockIdx.x * PX_THREADS + threadIdx.x;
-	if (c >= ncell)
+	const u32 total = incl[ncell - 1];
+	u32 k = blockIdx.x * PX_THREADS + threadIdx.x;
+	if (k >= total || k >= cap)
 		return;
-	u32 m = cchunks[c], base = incl[c] - m, s = rstart[c];
-	for (u32 j = 0; j < m; j++)
-		if (base + j < cap)
-			prefix[base + j] = s + 64u * j;
+	u32 lo = 0, hi = ncell - 1; // smallest c with incl[c] > k
+	while (lo < hi) {
+		u32 mid = (lo + hi) >> 1;
+		if (incl[mid] > k)
+			hi = mid;
+		else
+			lo = mid + 1;
+	}
+	const u32 c = lo;
+	const u32 j = k - (incl[c] - cchunks[c]);
+	prefix[k] = rstart[c] + 64u * j;
 }
 
 static int key_bits(u32 nkeys)
@@ -117,9 +126,7 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 	int rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->rmap[0], (size_t)n * 8)))
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->rstart, (size_t)ncell * 4)))
-		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->rspan, (size_t)ncell * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->rstart, (size_t)ncell * 8))) // run starts, then run ends
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->cchunks, (size_t)ncell * 4)))
 		return rc;
@@ -132,19 +139,25 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 	if (rc)
 		return rc;
 	UGRT_HIP(hipMemcpyAsync(d_map, tmp, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-	UGRT_HIP(hipMemsetAsync(ctx->rstart.p, 0, (size_t)ncell * 4, st));
-	UGRT_HIP(hipMemsetAsync(ctx->rspan.p, 0, (size_t)ncell * 4, st));
+	u32 *rstart = (u32 *)ctx->rstart.p, *rend = rstart + ncell;
+	UGRT_HIP(hipMemsetAsync(rstart, 0, (size_t)ncell * 8, st));
 	hipLaunchKernelGGL(k_ray_runs, dim3((n + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
-			   (const u32 *)(d_map + n), n, (u32 *)ctx->rstart.p, (u32 *)ctx->rspan.p);
+			   (const u32 *)(d_map + n), n, rstart, rend);
 	UGRT_HIP(hipGetLastError());
 	hipLaunchKernelGGL(k_chunk_count, dim3((ncell + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
-			   (const u32 *)ctx->rstart.p, (const u32 *)ctx->rspan.p, ncell, (u32 *)ctx->cchunks.p);
+			   (const u32 *)rstart, (const u32 *)rend, ncell, (u32 *)ctx->cchunks.p);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, (const u32 *)ctx->cchunks.p, (u32 *)ctx->cbase.p, ncell)))
 		return rc;
-	hipLaunchKernelGGL(k_chunk_emit, dim3((ncell + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
-			   (const u32 *)ctx->rstart.p, (const u32 *)ctx->cchunks.p, (const u32 *)ctx->cbase.p, ncell,
-			   prefix_capacity, d_prefix_map);
+	{
+		// at most n/64 + ncell chunks exist; the kernel reads the exact count on the device
+		u32 maxchunks = n / 64u + ncell;
+		if (maxchunks > prefix_capacity)
+			maxchunks = prefix_capacity;
+		hipLaunchKernelGGL(k_chunk_emit, dim3((maxchunks + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
+				   (const u32 *)ctx->rstart.p, (const u32 *)ctx->cchunks.p, (const u32 *)ctx->cbase.p,
+				   ncell, prefix_capacity, d_prefix_map);
+	}
 	UGRT_HIP(hipGetLastError());
 	// h_numCudaBlocks, decision_data.h:264
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 11, (u32 *)ctx->cbase.p + (ncell - 1), 4, hipMemcpyDeviceToHost, st));

@@ -897,9 +897,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	}
 	const u32 ncellk = C + 2; // + sentinel + "not traced"
 	const size_t maxg = (size_t)n / 64 + C + 1; // beams
-	if ((rc = ugrt_buf_reserve(ctx, ctx->sstart, (size_t)ncellk * 4)))
-		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->send, (size_t)ncellk * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sstart, (size_t)ncellk * 8))) // run starts, then run ends
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->scnt, (size_t)C * 8)))
 		return rc;
@@ -907,17 +905,15 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sdesc, maxg * sizeof(GBox))))
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->tbcnt, maxg * 4)))
-		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->tbincl, maxg * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->tbcnt, maxg * 8))) // candidate run starts, then ends, per beam
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, maxg * 8)))
 		return rc;
 	u64 *k0 = (u64 *)ctx->skey[0].p, *k1 = (u64 *)ctx->skey[1].p;
 	u32 *v0 = (u32 *)ctx->sval[0].p, *v1 = (u32 *)ctx->sval[1].p;
-	u32 *rstart = (u32 *)ctx->sstart.p, *rend = (u32 *)ctx->send.p;
+	u32 *rstart = (u32 *)ctx->sstart.p, *rend = rstart + ncellk;
 	u32 *gcnt = (u32 *)ctx->scnt.p, *icnt = gcnt + C, *gincl = (u32 *)ctx->sbase.p, *iincl = gincl + C;
-	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = (u32 *)ctx->tbincl.p;
+	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = pstart + maxg;
 	GBox *boxes = (GBox *)ctx->sdesc.p;
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
 	// 1. rays: (cell, direction code) order, runs per cell, beams
@@ -927,8 +923,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_sort_pairs64(ctx, k0, k1, v0, v1, n, 30 + bits_of(ncellk))))
 		return rc;
-	UGRT_HIP(hipMemsetAsync(rstart, 0, (size_t)ncellk * 4, st));
-	UGRT_HIP(hipMemsetAsync(rend, 0, (size_t)ncellk * 4, st));
+	UGRT_HIP(hipMemsetAsync(rstart, 0, (size_t)ncellk * 8, st));
 	hipLaunchKernelGGL(k_shadow_runs, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 			   (const u64 *)k1, n, rstart, rend);
 	UGRT_HIP(hipGetLastError());
@@ -1000,8 +995,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
 				       (u32 *)ctx->tval[1].p, P, bits_of(G))))
 		return rc;
-	UGRT_HIP(hipMemsetAsync(pstart, 0, (size_t)G * 4, st));
-	UGRT_HIP(hipMemsetAsync(pend, 0, (size_t)G * 4, st));
+	UGRT_HIP(hipMemsetAsync(pstart, 0, maxg * 8, st));
 	hipLaunchKernelGGL(k_pair_runs, dim3((P + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 			   (const u32 *)ctx->tkey[1].p, P, pstart, pend);
 	UGRT_HIP(hipGetLastError());

@@ -128,7 +128,6 @@ def add_room(mesh, n=40):
     """
     add_box(mesh, (0, 0, 0), (28, 26, 9), n, 1, faces="XyY")
     add_box(mesh, (0, 0, 0), (28, 26, 9), n, 0, faces="z")
-    add_box(mesh, (0, 0, 0), (28, 26, 9), n, 0, faces="z")
     add_box(mesh, (0, 0, 0), (28, 26, 9), n, 2, faces="Z")
 
 

@@ -14,11 +14,23 @@
 // wave itself (trace_kernel.cu:151-175) and read back as LDS broadcasts.
 // Waves are persistent: the launch is sized to the chip and each wave strides
 // over the work list, whose length stays on the device.
+#include <cstdlib>
+
 #include "ugrt_dev.h"
 
 #define SEG 256u          // triangles per primary work item
 #define TRI_STRIDE 12     // floats per staged triangle (9 used, 48 B: ds_read_b128 x3)
 #define WL_THREADS 256
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Work lists
+// are ordered so that neighbours share data (same cell, same triangle batch, same beam), so the
+// persistent waves take CONTIGUOUS slices per XCD: logical id = (b % 8) * (grid/8) + b / 8.
+// Placement only affects speed, never results.
+__device__ __forceinline__ u32 d_xcd_block()
+{
+	const u32 g = gridDim.x, b = blockIdx.x;
+	return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
+}
 
 struct WItem {
 	u32 cell;  // primary: screen cell; shadow: chunk index
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(64) void k_trace_primary(CamBlock cam, const float 
 	const int lane = threadIdx.x;
 	const u32 nitems = *nitems_p;
 	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
-	for (u32 it = blockIdx.x; it < nitems; it += gridDim.x) {
+	for (u32 it = d_xcd_block(); it < nitems; it += gridDim.x) {
 		const WItem w = items[it];
 		const int bx = (int)(w.cell / (u32)cam.nby), by = (int)(w.cell % (u32)cam.nby);
 		const int col = bx * 8 + (lane & 7), row = by * 8 + (lane >> 3);
@@ -666,7 +678,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 	const u32 total = iincl[C - 1];
 	const int lane = threadIdx.x;
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
-	for (u32 it = blockIdx.x; it < total; it += gridDim.x) {
+	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
 		const u32 c = d_find_cell(iincl, C, it);
 		const u32 sp = span[c];
 		const u32 nb = (sp + 63u) / 64u;
@@ -785,7 +797,7 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 	const u32 total = xincl[G - 1];
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
 	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
-	for (u32 it = blockIdx.x; it < total; it += gridDim.x) {
+	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
 		const u32 g = d_find_cell(xincl, G, it);
 		const u32 nseg = (pend[g] - pstart[g] + XSEG - 1) / XSEG;
 		const u32 sgm = it - (xincl[g] - nseg);
@@ -1038,9 +1050,7 @@ __device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
 	return d_clampi(c, 0, g.dims[k] - 1);
 }
 
-#define DDA_COOP 8u  // cells with at least this many triangles are tested by the whole wave
 #define DDA_AHEAD 4   // cells planned (and their headers fetched) per round trip
-#define DDA_RPW 16u   // secondary rays per wave
 
 __device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long v)
 {
@@ -1090,7 +1100,8 @@ __global__ __launch_bounds__(64) void k_trace_dda(DGrid g, const u32 *__restrict
 						   const float4 *__restrict__ rec,
 						   const float *__restrict__ rays, const u32 *__restrict__ list,
 						   const u32 *__restrict__ count_p, float *__restrict__ hit_t,
-						   int *__restrict__ hit_id, unsigned long long *__restrict__ counters)
+						   int *__restrict__ hit_id, unsigned long long *__restrict__ counters,
+						   u32 DDA_RPW, u32 DDA_COOP)
 {
 	const int lane = threadIdx.x;
 	const u32 count = *count_p;
@@ -1312,11 +1323,21 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
 	}
 	UGRT_HIP(hipGetLastError());
+	// rays per wave / list length from which the whole wave tests a cell (tunable for experiments)
+	u32 DDA_RPW = 32u, DDA_COOP = 8u;
+	if (const char *e = getenv("UGRT_DDA_RPW"))
+		DDA_RPW = (u32)atoi(e);
+	if (const char *e = getenv("UGRT_DDA_COOP"))
+		DDA_COOP = (u32)atoi(e);
+	if (DDA_RPW < 1u || DDA_RPW > 64u)
+		DDA_RPW = 32u;
+	if (DDA_COOP < 1u)
+		DDA_COOP = 1u;
 	const int blocks = launch_blocks_for((u32)ctx->npix / DDA_RPW + 1u);
 #define UGRT_LAUNCH_DDA(CNTV, RECV, DC)                                                                              \
 	hipLaunchKernelGGL((k_trace_dda<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
 			   d_offset, d_vertlist, d_trilist, rec, d_rays, (const u32 *)list, (const u32 *)dcount,     \
-			   d_hit_t, d_hit_id, DC)
+			   d_hit_t, d_hit_id, DC, DDA_RPW, DDA_COOP)
 	if (counting) {
 		// counting variant (never the timed one): same traversal + three atomics per ray
 		UGRT_HIP(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), ctx->stream));

@@ -358,3 +358,28 @@ def test_full_size_bench_workload(ugrt, O, torch):
     np.testing.assert_array_equal(r.hit_t.cpu().numpy()[a:b].view(np.uint32), want["hit_t"][a:b].view(np.uint32))
     np.testing.assert_array_equal(r.image.cpu().numpy()[3 * a:3 * b], want["image"][3 * a:3 * b])
     assert (pr["id"][a:b] >= 0).sum() > 1000 and want["is_shadowed"][a:b].sum() > 100
+
+
+def test_gather_path_without_records(ugrt, O, torch):
+    """When the caller's vertex/face arrays are not the ones the grids were last built from, the tracers fall
+    back to gathering 3 indices + 3 vertices per reference (the reference's own staging); same results."""
+    s = scene(ugrt, "hall")
+    W, H, lg, ud = 256, 256, (64, 64), (32, 32, 16)
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    verts2, faces2 = r.d_verts.clone(), r.d_faces.clone()
+    for name in ("trace_primary", "trace_shadow", "trace_dda"):
+        orig = getattr(ctx, name)
+
+        def patched(*a, _orig=orig):
+            a = [verts2 if x is r.d_verts else faces2 if x is r.d_faces else x for x in a]
+            return _orig(*a)
+
+        setattr(ctx, name, patched)
+    setup = setup_for(ugrt, s, "ref")
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud)
+    np.testing.assert_array_equal(r.t.cpu().numpy().view(np.uint32), want["primary"]["t"].view(np.uint32))
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"])
+    np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want["hit_id"])
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])

@@ -149,12 +149,20 @@ def main():
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, args.gpus))
     dist = None
+    # Rehearsal on a ONE-GPU box (UGRT_BENCH_REHEARSE=1): every rank uses device 0 and the collectives go
+    # through gloo with host staging.  It exercises the multi-rank code path, not RCCL, and is never a result.
+    rehearse = os.environ.get("UGRT_BENCH_REHEARSE", "") == "1"
+    if rehearse:
+        local = 0
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a GPU: libugrt has no CPU fallback"
     torch.cuda.set_device(local)
 
@@ -173,7 +181,7 @@ def main():
     flags = ugrt.FLAG_SHADOW_ALL_CHUNKS
     ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
     r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
-    gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world)
+    gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world, host_staging=rehearse)
 
     reflect = not args.no_reflect
     if args.animate:
@@ -228,7 +236,7 @@ def main():
     prof = ctx.prof_get()
     ctx.prof_enable(False)
 
-    tot = torch.tensor([elapsed, float(rays_rank)], dtype=torch.float64, device=ctx.device)
+    tot = torch.tensor([elapsed, float(rays_rank)], dtype=torch.float64, device="cpu" if rehearse else ctx.device)
     if dist is not None:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -262,7 +270,10 @@ def main():
     roofline = dict(bound="hbm", kernel={"trace_primary": "k_trace_primary", "trace_shadow": "k_trace_shadow",
                                          "shadow_cull": "k_shadow_cull", "trace_dda": "k_trace_dda"}[dom],
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
-                    traffic=traffic, algorithmic_bytes_per_launch=int(abytes[dom]), ms_per_launch=round(dom_ms, 4))
+                    traffic=traffic, algorithmic_bytes_per_launch=int(abytes[dom]), ms_per_launch=round(dom_ms, 4),
+                    note="algorithmic bytes are SURVEY 8(d)'s (every staged reference = 52 B, reuse not discounted); "
+                         "frac > 1 means the kernel reads each triangle once per cell instead of once per chunk: "
+                         "compare with traffic (PMC, profiles/)")
 
     cpu = None
     if world == 1 and args.cpu_seconds > 0:
@@ -284,7 +295,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a result)",
         "config": {
             "workload": ("BASELINE configs[%d] stand-in: procedural '%s' scene, %d triangles, %dx%d, primary + "
                          "shadow (1 light, all chunks traced)%s; all grids rebuilt every frame%s"

@@ -11,4 +11,5 @@ r.display(setup, reflect=True)
 ctx.synchronize()
 st = ctx.stats()
 print("stats", st)
-print("shadow items", st[1], "chunks traced", st[2], "tris loaded", st[6], "survivors", st[7], "shadowed px", int(r.is_shadowed.sum()))
+print("shadow beams", st[1], "chunks traced", st[2], "candidate pairs", st[7], "shadowed px", int(r.is_shadowed.sum()),
+      "| dda tests", st[3], "cells", st[4], "rays", st[5])

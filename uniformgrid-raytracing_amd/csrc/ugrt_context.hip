@@ -125,8 +125,7 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 		buf_free(G.val[1]);
 		buf_free(G.span);
 		buf_free(G.offset);
-		buf_free(G.cstart);
-	}
+		}
 	buf_free(ctx->temp);
 	buf_free(ctx->trirec);
 	buf_free(ctx->witems);
@@ -135,8 +134,6 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->best);
 	buf_free(ctx->rmap[0]);
 	buf_free(ctx->rmap[1]);
-	buf_free(ctx->rspan);
-	buf_free(ctx->roffset);
 	buf_free(ctx->rstart);
 	buf_free(ctx->cchunks);
 	buf_free(ctx->cbase);
@@ -146,7 +143,6 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->sval[1]);
 	buf_free(ctx->sdesc);
 	buf_free(ctx->sstart);
-	buf_free(ctx->send);
 	buf_free(ctx->scnt);
 	buf_free(ctx->sbase);
 	buf_free(ctx->tkey[0]);
@@ -154,8 +150,6 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->tval[0]);
 	buf_free(ctx->tval[1]);
 	buf_free(ctx->tbcnt);
-	buf_free(ctx->tbincl);
-	buf_free(ctx->tsph);
 	if (ctx->h_pinned)
 		(void)hipHostFree(ctx->h_pinned);
 	if (ctx->d_small)
@@ -213,7 +207,6 @@ extern "C" int ugrt_upload_camera(ugrt_ctx *ctx, const float camcoords[64])
 	int rc = ugrt_camera_direction_table(camcoords, t.v);
 	if (rc)
 		return rc;
-	memcpy(ctx->cam.tex, t.v, sizeof(t.v));
 	UGRT_HIP(hipSetDevice(ctx->device));
 	hipLaunchKernelGGL(k_store_table, dim3(1), dim3(128), 0, ctx->stream, t, ugrt_ctx_tex(ctx));
 	UGRT_HIP(hipGetLastError());

@@ -14,7 +14,6 @@
 // kernarg segment and is read with scalar loads into SGPRs.
 struct CamBlock {
 	float cc[64];   // dd_camcoords
-	float tex[100]; // texdir nodes, [5][5][4]
 	float light[4]; // dd_light_position[0..2]
 	int W, H, nbx, nby;
 };
@@ -27,7 +26,7 @@ struct DevBuf {
 struct Grid {
 	DevBuf rng, sizes, scan;          // per triangle
 	DevBuf key[2], val[2];            // per ref, ping-pong for the radix sort
-	DevBuf span, offset, cstart;      // per cell
+	DevBuf span, offset;              // per cell (span buffer also holds run starts + cells_used)
 	u32 *keys = nullptr, *vals = nullptr; // sorted result (one of key[i]/val[i])
 	u32 R = 0, C = 0, cells_used = 0;
 	int dims[3] = { 0, 0, 0 };
@@ -57,16 +56,15 @@ struct ugrt_ctx {
 	DevBuf witems, wcount, wscan; // tracer work lists
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)
-	DevBuf rspan, roffset, rstart, cchunks, cbase; // ray runs per light cell
-	DevBuf skey[2], sval[2], sdesc, sstart, send, scnt, sbase; // shadow tracer's private ray re-grouping
-	DevBuf tkey[2], tval[2], tbcnt, tbincl, tsph;              // ... and triangle re-ordering + batch spheres
+	DevBuf rstart, cchunks, cbase; // ray runs per light cell (sort_rays)
+	DevBuf skey[2], sval[2], sdesc, sstart, scnt, sbase; // shadow tracer: re-grouped rays, beams, counts
+	DevBuf tkey[2], tval[2], tbcnt;                      // shadow tracer: candidate pairs, runs per beam
 	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
 	u32 *d_small = nullptr;       // 16 u32 of device scratch (totals)
 	bool prof_on = false;
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;
 	unsigned long long stats[8] = { 0 };
-	unsigned long long shadow_stats[5] = { 0 }; // COUNT_WORK: items, spheres tested, batches loaded, survivors, rounds
 };
 
 #define UGRT_HIP(call)                                                                            \

@@ -26,8 +26,11 @@ def weak_scaling_resolution(world, base=(1920, 1080)):
 class BandGather:
     """Gathers every rank's RGB band into rank 0's full image with one collective."""
 
-    def __init__(self, dist, torch, device, width, nby, rank, world):
+    def __init__(self, dist, torch, device, width, nby, rank, world, host_staging=False):
         self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.image_device = device
+        if host_staging:  # backends without device-tensor gather (gloo): stage the bands through the host
+            device = torch.device("cpu")
         self.width, self.nby = width, nby
         self.bands = [band_rows(r, world, nby) for r in range(world)]
         self.max_bytes = max(e - b for b, e in self.bands) * 8 * width * 3
@@ -46,7 +49,7 @@ class BandGather:
         n = self.band_bytes(self.rank)
         if self.world == 1:
             return image
-        self.send[:n].copy_(image[off:off + n])
+        self.send[:n].copy_(image[off:off + n])  # (device -> host when staging)
         self.dist.gather(self.send, self.recv, dst=0)
         if self.rank == 0:
             for r in range(1, self.world):

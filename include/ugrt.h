@@ -138,6 +138,11 @@ const int *ugrt_scene_materiallist_index(const ugrt_scene *s);  /* h_materiallis
 const float *ugrt_scene_materiallist(const ugrt_scene *s);      /* h_materiallist [6M] Ka,Kd */
 /* obj_material.reflect of the mtllib (obj_parser.h:53, token "r"), [mtl_count] */
 const float *ugrt_scene_reflectlist(const ugrt_scene *s, int *mtl_count);
+/* Binary cache of a loaded scene (the strtok parser takes seconds on 1 M triangles).
+ * Little-endian: "UGRTSCN1", counts, then the flat lists exactly as the accessors return them.
+ * load_cache replaces the scene's contents; a truncated or foreign file gives UGRT_EIO. */
+int ugrt_scene_save_cache(const ugrt_scene *s, const char *path);
+int ugrt_scene_load_cache(ugrt_scene *s, const char *path);
 /* xMin..zMax, scene.h:43 */
 int ugrt_scene_bounds(const ugrt_scene *s, float bbmin[3], float bbmax[3]);
 void ugrt_scene_destroy(ugrt_scene *s);

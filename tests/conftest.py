@@ -11,6 +11,13 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the built library is git-ignored: a fresh checkout gets it here (hipcc cross-compiles without a GPU)
+    lib = os.path.join(ROOT, "uniformgrid-raytracing_amd", "libugrt.so")
+    if not os.path.exists(lib):
+        import subprocess
+
+        subprocess.run(["make", "-j", "6", "-C", os.path.join(ROOT, "uniformgrid-raytracing_amd", "csrc")], check=True,
+                       capture_output=True)
 
 
 def _have_gpu():

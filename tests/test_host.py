@@ -135,3 +135,42 @@ def test_ppm_matches_oracle(ugrt, O, tmp_path):
     assert a.startswith(b"P3\n24 16\n255\n\n0 9 10 99 100 255 ")
     with pytest.raises(ugrt.UgrtError):
         ugrt.write_ppm(tmp_path / "nodir" / "c.ppm", img)
+
+
+def test_scene_cache_roundtrip(ugrt, tmp_path):
+    s = ugrt.scenes.crash(str(tmp_path), scale=0.02)
+    m = ugrt.Model()
+    m.some_material(s["mat"])
+    m.load_model(s["obj"])
+    m.save_cache(tmp_path / "scene.bin")
+    m2 = ugrt.Model()
+    m2.load_cache(tmp_path / "scene.bin")
+    for name in ("h_vertexlist", "h_facelist", "h_materiallist_index", "h_materiallist", "h_reflectlist"):
+        np.testing.assert_array_equal(getattr(m, name), getattr(m2, name))
+    assert m2.num_materials == m.num_materials == 6
+    np.testing.assert_array_equal(np.concatenate(m.bounds()), np.concatenate(m2.bounds()))
+    # truncated and foreign files are rejected
+    raw = (tmp_path / "scene.bin").read_bytes()
+    (tmp_path / "cut.bin").write_bytes(raw[: len(raw) // 2])
+    (tmp_path / "bad.bin").write_bytes(b"NOTACACHE" + raw[9:])
+    for f in ("cut.bin", "bad.bin", "missing.bin"):
+        with pytest.raises(ugrt.UgrtError) as e:
+            ugrt.Model().load_cache(tmp_path / f)
+        assert e.value.code == ugrt.UGRT_EIO
+
+
+def test_dynamic_directory_frames(ugrt, O, tmp_path):
+    """Model::tmp_model (scene.h:70): <dir>/f_<i>.obj replaces the vertices, faces stay."""
+    s = ugrt.scenes.hall(str(tmp_path), scale=0.05)
+    os.rename(s["obj"], tmp_path / "f_0.obj")
+    txt = (tmp_path / "f_0.obj").read_text().splitlines()
+    moved = [("v %.6f %.6f %.6f" % tuple(float(x) + 0.25 for x in l.split()[1:])) if l.startswith("v ") else l for l in txt]
+    (tmp_path / "f_1.obj").write_text("\n".join(moved) + "\n")
+    m = ugrt.Model(frames=2)
+    m.load_model(tmp_path / "f_0.obj")
+    v0, f0 = m.h_vertexlist.copy(), m.h_facelist.copy()
+    m.tmp_model(tmp_path, 1)
+    np.testing.assert_allclose(m.h_vertexlist, v0 + np.float32(0.25), atol=1e-5)
+    np.testing.assert_array_equal(m.h_facelist, f0)
+    with pytest.raises(ugrt.UgrtError):
+        m.tmp_model(tmp_path, 7)

@@ -97,6 +97,8 @@ PROTOTYPES = {
     "ugrt_scene_materiallist_index": (_P, [_P]),
     "ugrt_scene_materiallist": (_P, [_P]),
     "ugrt_scene_reflectlist": (_P, [_P, C.POINTER(C.c_int)]),
+    "ugrt_scene_save_cache": (C.c_int, [_P, C.c_char_p]),
+    "ugrt_scene_load_cache": (C.c_int, [_P, C.c_char_p]),
     "ugrt_scene_bounds": (C.c_int, [_P, _F3, _F3]),
     "ugrt_scene_destroy": (None, [_P]),
     "ugrt_camera_set": (C.c_int, [C.POINTER(CameraStruct), _F3, _F3, _F3, C.c_float, C.c_float, C.c_float, C.c_float]),

@@ -333,6 +333,75 @@ extern "C" int ugrt_scene_load_frame(ugrt_scene *s, const char *dir, int frame)
 	return UGRT_OK;
 }
 
+// ---------------------------------------------------------------------------
+// binary scene cache
+// ---------------------------------------------------------------------------
+static const char CACHE_MAGIC[8] = { 'U', 'G', 'R', 'T', 'S', 'C', 'N', '1' };
+
+template <typename T> static bool put_vec(FILE *fp, const std::vector<T> &v)
+{
+	uint64_t n = v.size();
+	return fwrite(&n, 8, 1, fp) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, fp) == n);
+}
+template <typename T> static bool get_vec(FILE *fp, std::vector<T> &v, uint64_t limit)
+{
+	uint64_t n = 0;
+	if (fread(&n, 8, 1, fp) != 1 || n > limit)
+		return false;
+	v.resize(n);
+	return n == 0 || fread(v.data(), sizeof(T), n, fp) == n;
+}
+
+extern "C" int ugrt_scene_save_cache(const ugrt_scene *s, const char *path)
+{
+	if (!s || !path)
+		return ugrt_fail(UGRT_EINVAL, "scene_save_cache: null argument");
+	FILE *fp = fopen(path, "wb");
+	if (!fp)
+		return ugrt_fail(UGRT_EIO, "scene_save_cache: cannot open %s: %s", path, strerror(errno));
+	int32_t nm = s->num_materials;
+	bool ok = fwrite(CACHE_MAGIC, 1, 8, fp) == 8 && fwrite(&nm, 4, 1, fp) == 1 && fwrite(s->bbmin, 4, 3, fp) == 3 &&
+		  fwrite(s->bbmax, 4, 3, fp) == 3 && put_vec(fp, s->vertexlist) && put_vec(fp, s->facelist) &&
+		  put_vec(fp, s->matidx) && put_vec(fp, s->materiallist) && put_vec(fp, s->reflect);
+	ok = (fclose(fp) == 0) && ok;
+	if (!ok)
+		return ugrt_fail(UGRT_EIO, "scene_save_cache: short write to %s", path);
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_scene_load_cache(ugrt_scene *s, const char *path)
+{
+	if (!s || !path)
+		return ugrt_fail(UGRT_EINVAL, "scene_load_cache: null argument");
+	FILE *fp = fopen(path, "rb");
+	if (!fp)
+		return ugrt_fail(UGRT_EIO, "scene_load_cache: cannot open %s: %s", path, strerror(errno));
+	char magic[8];
+	ugrt_scene t;
+	int32_t nm = 0;
+	const uint64_t lim = (uint64_t)1 << 33;
+	bool ok = fread(magic, 1, 8, fp) == 8 && memcmp(magic, CACHE_MAGIC, 8) == 0 && fread(&nm, 4, 1, fp) == 1 &&
+		  fread(t.bbmin, 4, 3, fp) == 3 && fread(t.bbmax, 4, 3, fp) == 3 && get_vec(fp, t.vertexlist, lim) &&
+		  get_vec(fp, t.facelist, lim) && get_vec(fp, t.matidx, lim) && get_vec(fp, t.materiallist, lim) &&
+		  get_vec(fp, t.reflect, lim);
+	fclose(fp);
+	ok = ok && nm >= 0 && t.materiallist.size() == (size_t)nm * 6 && t.vertexlist.size() % 3 == 0 &&
+	     t.facelist.size() == t.matidx.size() * 3;
+	if (ok) {
+		const size_t nv = t.vertexlist.size() / 3;
+		for (int idx : t.facelist)
+			if (idx < 0 || (size_t)idx >= nv) {
+				ok = false;
+				break;
+			}
+	}
+	if (!ok)
+		return ugrt_fail(UGRT_EIO, "scene_load_cache: %s is not a valid ugrt scene cache", path);
+	t.num_materials = nm;
+	*s = t;
+	return UGRT_OK;
+}
+
 extern "C" int ugrt_scene_counts(const ugrt_scene *s, int *nv, int *nf, int *nm)
 {
 	if (!s)

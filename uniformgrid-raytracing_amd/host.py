@@ -35,6 +35,12 @@ class Model:
     def load_model(self, path):
         check(lib.ugrt_scene_load_model(self._h, str(path).encode()))
 
+    def save_cache(self, path):
+        check(lib.ugrt_scene_save_cache(self._h, str(path).encode()))
+
+    def load_cache(self, path):
+        check(lib.ugrt_scene_load_cache(self._h, str(path).encode()))
+
     def tmp_model(self, directory, i):
         check(lib.ugrt_scene_load_frame(self._h, str(directory).encode(), int(i)))
 

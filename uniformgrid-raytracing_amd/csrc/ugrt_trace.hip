@@ -471,7 +471,7 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 // The cull is conservative with margins far above fp32 rounding, so the flags do not change.
 #define GCHUNK 256u // beams a cull work item streams past its 64 triangles
 
-struct GBox { // one beam (<= 64 re-grouped rays of one light cell)
+struct GBox { // one beam (re-grouped rays of one light cell)
 	float cx, cy, cz; // centre of the direction box
 	float rx, ry, rz; // half widths (slightly widened)
 	u32 ray_start;    // into the re-grouped ray list
@@ -547,12 +547,12 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const u64 *__restric
 // per light cell: number of beams, and number of cull items = triangle batches x beam chunks
 __global__ __launch_bounds__(WL_THREADS) void k_shadow_count(const u32 *__restrict__ span, const u32 *__restrict__ rstart,
 							      const u32 *__restrict__ rend, u32 C, u32 *__restrict__ gcnt,
-							      u32 *__restrict__ icnt)
+							      u32 *__restrict__ icnt, u32 beam)
 {
 	u32 c = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (c >= C)
 		return;
-	u32 g = (rend[c] - rstart[c] + 63u) / 64u;
+	u32 g = (rend[c] - rstart[c] + beam - 1u) / beam;
 	u32 nb = (span[c] + 63u) / 64u;
 	gcnt[c] = g;
 	icnt[c] = nb * ((g + GCHUNK - 1) / GCHUNK);
@@ -600,41 +600,51 @@ __device__ __forceinline__ ShadowRay d_shadow_ray(const CamBlock &cam, const flo
 	return r;
 }
 
-// one wave per beam: direction box of its rays
+// one wave per beam (`beam` = 64..256 re-grouped rays of one light cell): direction box of its rays
 __global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__restrict__ gincl, u32 C,
 						     const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
 						     const u32 *__restrict__ ray_pixels, const float *__restrict__ t_value_list,
 						     const float *__restrict__ ray_direction_list,
-						     const float *__restrict__ cmPt, GBox *__restrict__ boxes)
+						     const float *__restrict__ cmPt, GBox *__restrict__ boxes, u32 beam)
 {
 	const u32 total = gincl[C - 1];
 	const int lane = threadIdx.x;
 	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
+	const float inf = __builtin_huge_valf();
 	for (u32 g = blockIdx.x; g < total; g += gridDim.x) {
 		const u32 c = d_find_cell(gincl, C, g);
-		const u32 ngrp = (rend[c] - rstart[c] + 63u) / 64u;
+		const u32 ngrp = (rend[c] - rstart[c] + beam - 1u) / beam;
 		const u32 j = g - (gincl[c] - ngrp);
-		const u32 start = rstart[c] + 64u * j;
+		const u32 start = rstart[c] + beam * j;
 		const u32 left = rend[c] - start;
-		const u32 cnt = left < 64u ? left : 64u;
-		const bool have = (u32)lane < cnt;
-		float rd[3] = { 0.0f, 0.0f, 0.0f };
-		if (have) {
-			ShadowRay r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm, (int)ray_pixels[start + lane]);
-			rd[0] = r.rd[0];
-			rd[1] = r.rd[1];
-			rd[2] = r.rd[2];
+		const u32 cnt = left < beam ? left : beam;
+		float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
+		for (u32 b = 0; b < cnt; b += 64) {
+			const bool have = b + (u32)lane < cnt;
+			float rd[3] = { 0.0f, 0.0f, 0.0f };
+			if (have) {
+				ShadowRay r =
+					d_shadow_ray(cam, t_value_list, ray_direction_list, cm, (int)ray_pixels[start + b + lane]);
+				rd[0] = r.rd[0];
+				rd[1] = r.rd[1];
+				rd[2] = r.rd[2];
+			}
+			const DirBox bx = d_dir_box(rd, have);
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				lo[k] = fminf(lo[k], bx.lo[k]);
+				hi[k] = fmaxf(hi[k], bx.hi[k]);
+			}
 		}
-		const DirBox bx = d_dir_box(rd, have);
 		if (lane == 0) {
 			GBox o;
-			o.cx = 0.5f * (bx.lo[0] + bx.hi[0]);
-			o.cy = 0.5f * (bx.lo[1] + bx.hi[1]);
-			o.cz = 0.5f * (bx.lo[2] + bx.hi[2]);
+			o.cx = 0.5f * (lo[0] + hi[0]);
+			o.cy = 0.5f * (lo[1] + hi[1]);
+			o.cz = 0.5f * (lo[2] + hi[2]);
 			// half widths, widened by far more than the rounding of centre and width
-			o.rx = 0.5f * (bx.hi[0] - bx.lo[0]) + 1e-6f;
-			o.ry = 0.5f * (bx.hi[1] - bx.lo[1]) + 1e-6f;
-			o.rz = 0.5f * (bx.hi[2] - bx.lo[2]) + 1e-6f;
+			o.rx = 0.5f * (hi[0] - lo[0]) + 1e-6f;
+			o.ry = 0.5f * (hi[1] - lo[1]) + 1e-6f;
+			o.rz = 0.5f * (hi[2] - lo[2]) + 1e-6f;
 			o.ray_start = start;
 			o.ray_count = cnt;
 			boxes[g] = o;
@@ -774,11 +784,11 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict_
 #define XSEG 256u // candidates per exact-pass work item
 
 __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
-								 u32 G, u32 *__restrict__ xcnt)
+								 const GBox *__restrict__ boxes, u32 G, u32 *__restrict__ xcnt)
 {
 	u32 g = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (g < G)
-		xcnt[g] = (pend[g] - pstart[g] + XSEG - 1) / XSEG;
+		xcnt[g] = ((pend[g] - pstart[g] + XSEG - 1) / XSEG) * ((boxes[g].ray_count + 63u) / 64u);
 }
 
 // EXACT pass: item -> (beam, segment of its candidate list); lane = ray, the reference's test
@@ -799,19 +809,22 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
 	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
 		const u32 g = d_find_cell(xincl, G, it);
+		const GBox bx = boxes[g];
 		const u32 nseg = (pend[g] - pstart[g] + XSEG - 1) / XSEG;
-		const u32 sgm = it - (xincl[g] - nseg);
+		const u32 nsub = (bx.ray_count + 63u) / 64u;
+		const u32 local = it - (xincl[g] - nseg * nsub);
+		const u32 sgm = local / nsub, sub = local % nsub; // the sub-groups of a beam share its candidate list
 		const u32 p0 = pstart[g] + sgm * XSEG;
 		const u32 p1 = (p0 + XSEG) < pend[g] ? (p0 + XSEG) : pend[g];
-		const GBox bx = boxes[g];
-		const bool have_ray = (u32)lane < bx.ray_count;
+		const bool have_ray = 64u * sub + (u32)lane < bx.ray_count;
 		ShadowRay r;
 		r.rd[0] = r.rd[1] = r.rd[2] = 0.0f;
 		r.distance_b = 0.0f;
 		r.pixel = 0;
 		bool done = true; // rayDoneMap == 2
 		if (have_ray) {
-			r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm, (int)ray_pixels[bx.ray_start + lane]);
+			r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm,
+					 (int)ray_pixels[bx.ray_start + 64u * sub + lane]);
 			// a ray already flagged by another segment of its beam needs no more tests
 			done = is_shadowed[r.pixel] == 1;
 		}
@@ -939,8 +952,14 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	hipLaunchKernelGGL(k_shadow_runs, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 			   (const u64 *)k1, n, rstart, rend);
 	UGRT_HIP(hipGetLastError());
+	// rays per beam: the cull pass costs (triangles of the cell) x (beams of the cell), the exact pass
+	// (candidate pairs) x (rays per beam); 128 balances the two on debris-like scenes
+	u32 beam = 128u;
+	if (const char *e = getenv("UGRT_SHADOW_BEAM"))
+		beam = (u32)atoi(e);
+	beam = beam < 64u ? 64u : (beam > 1024u ? 1024u : (beam + 63u) / 64u * 64u);
 	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
-			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt);
+			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt, beam);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, gcnt, gincl, C)))
 		return rc;
@@ -948,7 +967,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64), 0, st, ctx->cam,
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
-			   d_ray_dir, d_cam_position, boxes);
+			   d_ray_dir, d_cam_position, boxes, beam);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	// 2. cull pass -> (beam, triangle) candidate pairs; grows the pair buffer and repeats if it was too small
@@ -1013,7 +1032,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	UGRT_HIP(hipGetLastError());
 	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + G;
 	hipLaunchKernelGGL(k_pair_item_count, dim3((G + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)pstart, (const u32 *)pend, G, xcnt);
+			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, G)))
 		return rc;
@@ -1021,12 +1040,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	if (use_rec)
-		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(G + P / XSEG)), dim3(64), 0, st, ctx->cam,
+		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for((G + P / XSEG) * (beam / 64u))), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position);
 	else
-		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(G + P / XSEG)), dim3(64), 0, st, ctx->cam,
+		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for((G + P / XSEG) * (beam / 64u))), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position);

@@ -7,7 +7,7 @@ setup = ugrt.FrameSetup.from_scene(s)
 ctx = ugrt.Context(1920, 1080, light_grid=(128, 128), flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, uniform_dims=(128, 128, 64))
 r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
 ref = None
-for beam in (64, 128, 192, 256, 384, 512):
+for beam in (64, 512, 768, 1024, 1536, 2048, 4096):
     os.environ["UGRT_SHADOW_BEAM"] = str(beam)
     for _ in range(2):
         r.display(setup, reflect=True)

@@ -830,14 +830,23 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		}
 		if (__ballot(!done) == 0ull)
 			continue;
+		// the candidates were found for the whole beam; this wave's 64 (still undecided) rays are a
+		// narrower packet, so each staged candidate is culled once more against their own box
+		const DirBox box = d_dir_box(r.rd, !done);
 		bool hit = false;
 		for (u32 b = p0; b < p1; b += 64) {
-			const u32 cnt = (p1 - b) < 64u ? (p1 - b) : 64u;
-			__syncthreads();
-			if ((u32)lane < cnt) {
-				float t9[9];
+			const u32 ncand = (p1 - b) < 64u ? (p1 - b) : 64u;
+			bool keep = false;
+			float t9[9];
+			if ((u32)lane < ncand) {
 				d_load_triangle<REC>(rec, verts, tris, pair_tri[b + lane], lx, ly, lz, t9);
-				float4 *dst = reinterpret_cast<float4 *>(&lds[lane * TRI_STRIDE]);
+				keep = !d_cull(&t9[0], &t9[3], &t9[6], box);
+			}
+			const unsigned long long mask = __ballot(keep);
+			const u32 cnt = (u32)__popcll(mask);
+			__syncthreads();
+			if (keep) {
+				float4 *dst = reinterpret_cast<float4 *>(&lds[d_rank_in_mask(mask) * TRI_STRIDE]);
 				dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
 				dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
 				dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
@@ -952,12 +961,13 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	hipLaunchKernelGGL(k_shadow_runs, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 			   (const u64 *)k1, n, rstart, rend);
 	UGRT_HIP(hipGetLastError());
-	// rays per beam: the cull pass costs (triangles of the cell) x (beams of the cell), the exact pass
-	// (candidate pairs) x (rays per beam); 128 balances the two on debris-like scenes
-	u32 beam = 128u;
+	// rays per beam: the cull pass costs (triangles of the cell) x (beams of the cell); the exact pass
+	// re-culls the beam's candidates against each 64-ray sub-group, so its cost barely depends on the
+	// beam size.  ~1000 rays per beam is the measured optimum on the 1 M-triangle scene (tools/beam_sweep.py)
+	u32 beam = 1024u;
 	if (const char *e = getenv("UGRT_SHADOW_BEAM"))
 		beam = (u32)atoi(e);
-	beam = beam < 64u ? 64u : (beam > 1024u ? 1024u : (beam + 63u) / 64u * 64u);
+	beam = beam < 64u ? 64u : (beam > 8192u ? 8192u : (beam + 63u) / 64u * 64u);
 	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
 			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt, beam);
 	UGRT_HIP(hipGetLastError());

@@ -68,10 +68,14 @@ def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
     cells = r.d_map[n:2 * n][heads].long()
     C_l = lgi.num_cells
     sp = torch.where(cells < C_l, lspan[cells.clamp(max=C_l - 1)].long(), torch.zeros_like(cells))
-    # the shadow stage (24 N + sum_chunks(8 + 52 span)) runs as two kernels: the cull pass
-    # streams every (chunk, triangle) reference, the exact pass rebuilds the N rays and tests P candidates
-    out["shadow_cull"] = 8 * nch + 52 * int(sp.sum().item())
-    out["trace_shadow"] = 24 * n + 52 * int(ctx.stats()[7])
+    # SURVEY A11 prices the shadow STAGE at 24 N + sum_chunks(8 + 52 span): every 64-ray chunk re-stages its
+    # cell's whole list.  Here the stage is two kernels with their own units: the cull pass tests
+    # (triangle, beam) pairs (52 B reference each), the exact pass rebuilds the N rays and stages the
+    # candidate references of each beam once per 64-ray sub-group.
+    st = ctx.stats()
+    out["stage_shadow_A11"] = 24 * n + 8 * nch + 52 * int(sp.sum().item())
+    out["shadow_cull"] = 52 * int(st[6]) + 32 * int(st[1])
+    out["trace_shadow"] = 24 * n + 52 * int(st[7])
     tests, cells_visited, active = dda_counts
     out["trace_dda"] = 48 * active + 8 * cells_visited + 52 * tests
     out["_R_perspective"], out["_R_spherical"] = gi.total_refs, lgi.total_refs
@@ -267,13 +271,17 @@ def main():
             traffic = rec.get(key)
         except Exception:
             traffic = None
+    a11_ms = sum(stages.get(k, {}).get("ms_per_step", 0.0) for k in ("shadow_prep", "shadow_cull", "trace_shadow"))
+    roofline_stage = dict(stage="shadow (SURVEY A11: prep + cull + exact kernels)", algorithmic_bytes=int(abytes["stage_shadow_A11"]),
+                          ms=round(a11_ms, 4), achieved=round(abytes["stage_shadow_A11"] / (a11_ms * 1e-3) / 1e9, 2),
+                          unit="GB/s", frac=round(abytes["stage_shadow_A11"] / (a11_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) \
+        if a11_ms > 0 else None
     roofline = dict(bound="hbm", kernel={"trace_primary": "k_trace_primary", "trace_shadow": "k_trace_shadow",
                                          "shadow_cull": "k_shadow_cull", "trace_dda": "k_trace_dda"}[dom],
                     achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
                     traffic=traffic, algorithmic_bytes_per_launch=int(abytes[dom]), ms_per_launch=round(dom_ms, 4),
-                    note="algorithmic bytes are SURVEY 8(d)'s (every staged reference = 52 B, reuse not discounted); "
-                         "frac > 1 means the kernel reads each triangle once per cell instead of once per chunk: "
-                         "compare with traffic (PMC, profiles/)")
+                    note="algorithmic bytes: SURVEY 8(d) convention (a staged reference = 52 B, cache/LDS reuse not "
+                         "discounted) applied to the units THIS kernel processes; DESIGN.md section 5/8. traffic = PMC")
 
     cpu = None
     if world == 1 and args.cpu_seconds > 0:
@@ -308,6 +316,7 @@ def main():
             "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",
         },
         "roofline": roofline,
+        "roofline_stage": roofline_stage,
         "cpu_baseline": cpu,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},

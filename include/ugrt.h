@@ -74,6 +74,7 @@ enum {
 	UGRT_ST_ANIMATE,         /* copy_data_transform */
 	UGRT_ST_WORKLIST,        /* work-item list construction for the tracers */
 	UGRT_ST_SHADOW_CULL,     /* shadow tracer's (beam, triangle) cull pass */
+	UGRT_ST_SHADOW_PREP,     /* shadow tracer's private re-grouping: ray keys + sort, beams, candidate sort */
 	UGRT_ST_COUNT
 };
 
@@ -245,10 +246,10 @@ int ugrt_prof_reset(ugrt_ctx *ctx);
 /* total milliseconds and number of timed launches of a stage since the reset
  * (synchronises the stream) */
 int ugrt_prof_get(ugrt_ctx *ctx, int stage, double *ms_total, int *launches);
-/* counters of the last tracer launches: [0] primary work-item capacity, [1] shadow beams
- * (64-ray groups), [2] shadow chunks traced, [7] shadow (beam, triangle) candidate pairs that
- * reached the per-ray test; with UGRT_FLAG_COUNT_WORK also [3] DDA candidates tested,
- * [4] DDA cells visited, [5] DDA active rays */
+/* counters of the last tracer launches (synchronises the stream): [0] primary work-item
+ * capacity, [1] shadow beams, [2] shadow chunks traced, [6] shadow cull pass: (triangle, beam)
+ * tests, [7] shadow exact pass: candidates staged (candidate pairs x 64-ray sub-groups);
+ * with UGRT_FLAG_COUNT_WORK also [3] DDA candidates tested, [4] DDA cells visited, [5] DDA active rays */
 int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8]);
 
 #ifdef __cplusplus

@@ -47,7 +47,7 @@ FLAG_COUNT_WORK = 2
 GRID_PERSPECTIVE, GRID_SPHERICAL, GRID_UNIFORM = 0, 1, 2
 STAGES = [
     "build_count", "build_scan", "build_fill", "build_sort", "build_bounds", "trace_primary", "map_rays",
-    "sort_rays", "trace_shadow", "shade", "reflect_gen", "trace_dda", "animate", "worklist", "shadow_cull",
+    "sort_rays", "trace_shadow", "shade", "reflect_gen", "trace_dda", "animate", "worklist", "shadow_cull", "shadow_prep",
 ]
 
 

@@ -86,7 +86,7 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 	ctx->cam.H = cfg->height;
 	ctx->cam.nbx = nbx;
 	ctx->cam.nby = nby;
-	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 16 * sizeof(u32), hipHostMallocDefault);
+	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 32 * sizeof(u32), hipHostMallocDefault);
 	if (e == hipSuccess)
 		e = hipMalloc((void **)&ctx->d_small, (32 + 100) * sizeof(u32));
 	if (e != hipSuccess) {
@@ -320,6 +320,11 @@ extern "C" int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8])
 {
 	if (!ctx || !stats)
 		return ugrt_fail(UGRT_EINVAL, "stats_get: null argument");
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
 	memcpy(stats, ctx->stats, sizeof(ctx->stats));
+	if (ctx->stats[2]) { // the shadow tracer ran: its work counters were copied to pinned memory
+		memcpy(&stats[6], ctx->h_pinned + 14, 8);
+		memcpy(&stats[7], ctx->h_pinned + 16, 8);
+	}
 	return UGRT_OK;
 }

@@ -547,7 +547,8 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const u64 *__restric
 // per light cell: number of beams, and number of cull items = triangle batches x beam chunks
 __global__ __launch_bounds__(WL_THREADS) void k_shadow_count(const u32 *__restrict__ span, const u32 *__restrict__ rstart,
 							      const u32 *__restrict__ rend, u32 C, u32 *__restrict__ gcnt,
-							      u32 *__restrict__ icnt, u32 beam)
+							      u32 *__restrict__ icnt, u32 beam,
+							      unsigned long long *__restrict__ tests)
 {
 	u32 c = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (c >= C)
@@ -556,6 +557,8 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_count(const u32 *__restri
 	u32 nb = (span[c] + 63u) / 64u;
 	gcnt[c] = g;
 	icnt[c] = nb * ((g + GCHUNK - 1) / GCHUNK);
+	if (g && span[c])
+		atomicAdd(tests, (unsigned long long)span[c] * (unsigned long long)g); // cells that matter are few
 }
 
 // smallest c with incl[c] > x (incl = inclusive scan over C cells, x < incl[C-1])
@@ -784,11 +787,22 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict_
 #define XSEG 256u // candidates per exact-pass work item
 
 __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
-								 const GBox *__restrict__ boxes, u32 G, u32 *__restrict__ xcnt)
+								 const GBox *__restrict__ boxes, u32 G, u32 *__restrict__ xcnt,
+								 unsigned long long *__restrict__ staged)
 {
 	u32 g = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (g < G)
-		xcnt[g] = ((pend[g] - pstart[g] + XSEG - 1) / XSEG) * ((boxes[g].ray_count + 63u) / 64u);
+	unsigned long long mine = 0;
+	if (g < G) {
+		const u32 cand = pend[g] - pstart[g], nsub = (boxes[g].ray_count + 63u) / 64u;
+		xcnt[g] = ((cand + XSEG - 1) / XSEG) * nsub;
+		mine = (unsigned long long)cand * nsub;
+	}
+	// candidates staged by the exact pass (work accounting): one atomic per wave
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		mine += __shfl_xor(mine, m);
+	if ((threadIdx.x & 63) == 0 && mine)
+		atomicAdd(staged, mine);
 }
 
 // EXACT pass: item -> (beam, segment of its candidate list); lane = ray, the reference's test
@@ -949,7 +963,9 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	u32 *gcnt = (u32 *)ctx->scnt.p, *icnt = gcnt + C, *gincl = (u32 *)ctx->sbase.p, *iincl = gincl + C;
 	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = pstart + maxg;
 	GBox *boxes = (GBox *)ctx->sdesc.p;
-	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
+	unsigned long long *wcnt = (unsigned long long *)(ctx->d_small + 16); // [0] cull tests, [1] staged candidates
+	UGRT_HIP(hipMemsetAsync(wcnt, 0, 16, st));
+	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	// 1. rays: (cell, direction code) order, runs per cell, beams
 	hipLaunchKernelGGL(k_shadow_keys, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, ctx->cam,
 			   d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span, d_cam_position, k0,
@@ -969,7 +985,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		beam = (u32)atoi(e);
 	beam = beam < 64u ? 64u : (beam > 8192u ? 8192u : (beam + 63u) / 64u * 64u);
 	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
-			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt, beam);
+			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt, beam, wcnt);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, gcnt, gincl, C)))
 		return rc;
@@ -979,7 +995,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
 			   d_ray_dir, d_cam_position, boxes, beam);
 	UGRT_HIP(hipGetLastError());
-	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	// 2. cull pass -> (beam, triangle) candidate pairs; grows the pair buffer and repeats if it was too small
 	u32 *pcount = ctx->d_small + 1;
 	u32 P = 0;
@@ -1028,11 +1044,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	}
 	const u32 G = ctx->h_pinned[12];
 	ctx->stats[1] = G;
-	ctx->stats[7] = P;
 	if (P == 0 || G == 0)
 		return UGRT_OK;
 	// 3. candidates by beam
-	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
+	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
 				       (u32 *)ctx->tval[1].p, P, bits_of(G))))
 		return rc;
@@ -1042,11 +1057,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	UGRT_HIP(hipGetLastError());
 	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + G;
 	hipLaunchKernelGGL(k_pair_item_count, dim3((G + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt);
+			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt, wcnt + 1);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, G)))
 		return rc;
-	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 14, wcnt, 16, hipMemcpyDeviceToHost, st)); // read by ugrt_stats_get
+	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	if (use_rec)

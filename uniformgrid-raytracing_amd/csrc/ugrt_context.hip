@@ -21,7 +21,6 @@ static int check_device(int device)
 
 int ugrt_buf_reserve(ugrt_ctx *ctx, DevBuf &b, size_t bytes)
 {
-	(void)ctx;
 	if (bytes <= b.cap && b.p)
 		return UGRT_OK;
 	size_t want = bytes + bytes / 2;

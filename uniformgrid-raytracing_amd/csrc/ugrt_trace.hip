@@ -4,7 +4,7 @@
 // Mapping to CDNA4: the reference's 8x8-thread CUDA block per grid tile
 // (trace_kernel.cu:84, light_kernel.cu:52) is exactly one 64-lane wavefront,
 // so "block per cell" becomes "wave per work item" with no multi-wave
-// barriers.  A work item is (cell, run of <= SEG triangles of that cell): the
+// barriers.  A work item is (cell, one segment of that cell's triangles): the
 // reference gives a whole cell to one block, and border cells that collect
 // every clamped off-screen triangle then serialise the frame;
 // here long cells are cut into segments that run on different waves and are
@@ -18,7 +18,6 @@
 
 #include "ugrt_dev.h"
 
-#define SEG 256u          // triangles per primary work item
 #define TRI_STRIDE 12     // floats per staged triangle (9 used, 48 B: ds_read_b128 x3)
 #define WL_THREADS 256
 
@@ -35,7 +34,7 @@ __device__ __forceinline__ u32 d_xcd_block()
 struct WItem {
 	u32 cell;  // primary: screen cell; shadow: chunk index
 	u32 begin; // first ref
-	u32 count; // refs in this item (<= SEG)
+	u32 count; // refs in this item (at most one segment)
 	u32 multi; // primary: cell is split across items
 };
 
@@ -44,7 +43,7 @@ struct WItem {
 // ---------------------------------------------------------------------------
 // primary: one entry per cell of the band, x-major like the cell ids
 __global__ __launch_bounds__(WL_THREADS) void k_wl_count_primary(const u32 *__restrict__ span, int nby, int gy_lo,
-								  int rows, u32 ncell, u32 *__restrict__ cnt)
+								  int rows, u32 ncell, u32 *__restrict__ cnt, u32 SEG)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (i >= ncell)
@@ -57,7 +56,7 @@ __global__ __launch_bounds__(WL_THREADS) void k_wl_count_primary(const u32 *__re
 __global__ __launch_bounds__(WL_THREADS) void k_wl_fill_primary(const u32 *__restrict__ span,
 								 const u32 *__restrict__ offset, int nby, int gy_lo,
 								 int rows, u32 ncell, const u32 *__restrict__ cnt,
-								 const u32 *__restrict__ incl, WItem *__restrict__ items)
+								 const u32 *__restrict__ incl, WItem *__restrict__ items, u32 SEG)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (i >= ncell)
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(CamBlock cam, const flo
 							  const u32 *__restrict__ span,
 							  const u32 *__restrict__ value_list,
 							  const float *__restrict__ verts, const int *__restrict__ tris,
-							  PrimaryOut out, u64 *__restrict__ best, int p0, int npix)
+							  PrimaryOut out, u64 *__restrict__ best, int p0, int npix, u32 SEG)
 {
 	int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= npix)
@@ -406,6 +405,14 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	int rc = refs_of(ctx, d_span, d_offset, C, &R);
 	if (rc)
 		return rc;
+	// triangles per work item: long cells are cut into segments that run on different waves and are
+	// merged with atomicMin + a resolve pass; cells up to SEG triangles finish inside their one wave.
+	// Every cell of a closed scene carries the few hundred eye-plane-straddling triangles (Q9), so the
+	// cut-off sits above that baseline.
+	u32 SEG = 1024u;
+	if (const char *e = getenv("UGRT_PRIMARY_SEG"))
+		SEG = (u32)atoi(e);
+	SEG = SEG < 64u ? 64u : (SEG + 63u) / 64u * 64u;
 	const size_t cap = (size_t)ncell + R / SEG + 1;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->wcount, (size_t)ncell * 4)))
 		return rc;
@@ -417,12 +424,12 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	WItem *items = (WItem *)ctx->witems.p;
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
 	hipLaunchKernelGGL(k_wl_count_primary, dim3((ncell + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   d_span, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt);
+			   d_span, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt, SEG);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, cnt, incl, ncell)))
 		return rc;
 	hipLaunchKernelGGL(k_wl_fill_primary, dim3((ncell + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   d_span, d_offset, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt, incl, items);
+			   d_span, d_offset, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt, incl, items, SEG);
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	PrimaryOut out = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
@@ -443,7 +450,7 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
 	hipLaunchKernelGGL(k_resolve_primary, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
 			   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist, out,
-			   (u64 *)ctx->best.p, ctx->p0, ctx->npix);
+			   (u64 *)ctx->best.p, ctx->p0, ctx->npix, SEG);
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	ctx->stats[0] = cap; // upper bound of primary work items

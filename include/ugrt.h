@@ -240,7 +240,8 @@ int ugrt_animate(ugrt_ctx *ctx, float *d_vertlist, const float *d_orig_list, int
 		 float rot_factor);
 
 /* ---- profiling ---------------------------------------------------------- */
-/* hipEvent pairs around every stage, on the context's stream */
+/* hipEvent pairs around stages, on the context's stream.  on = 0: off; 1: every stage; otherwise a
+ * mask in which bit (s + 1) selects stage UGRT_ST_s */
 int ugrt_prof_enable(ugrt_ctx *ctx, int on);
 int ugrt_prof_reset(ugrt_ctx *ctx);
 /* total milliseconds and number of timed launches of a stage since the reset

@@ -383,3 +383,24 @@ def test_gather_path_without_records(ugrt, O, torch):
     np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"])
     np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want["hit_id"])
     np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+
+
+def test_overlapped_display_equals_sequential(ugrt, O, torch):
+    """Renderer(overlap=True) builds the light and uniform grids on a second stream/context; same frame."""
+    s = scene(ugrt, "crash")
+    W, H, lg, ud = 256, 144, (64, 64), (32, 32, 16)
+    setup = setup_for(ugrt, s, "ref")
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    ctx2 = ugrt.Context(W, H, light_grid=lg, uniform_dims=ud)
+    r2 = ugrt.Renderer(ctx2, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True)
+    for _ in range(3):  # several frames: the streams must stay ordered across frames
+        r2.display(setup, shadows=True, reflect=True)
+    r2.synchronize()
+    torch.cuda.synchronize()
+    for name in ("t", "is_shadowed", "hit_id", "hit_t", "intersect_id", "image"):
+        a, b = getattr(r, name).cpu().numpy(), getattr(r2, name).cpu().numpy()
+        np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8), err_msg=name)
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud)
+    np.testing.assert_array_equal(r2.image.cpu().numpy(), want["image"])

@@ -248,7 +248,7 @@ extern "C" int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out)
 // ---------------------------------------------------------------------------
 void ugrt_prof_begin(ugrt_ctx *ctx, int stage)
 {
-	if (!ctx->prof_on)
+	if (!((ctx->prof_mask >> stage) & 1u))
 		return;
 	ProfPair p;
 	if (!ctx->prof_pool.empty()) {
@@ -268,7 +268,7 @@ void ugrt_prof_begin(ugrt_ctx *ctx, int stage)
 
 void ugrt_prof_end(ugrt_ctx *ctx, int stage)
 {
-	if (!ctx->prof_on || ctx->prof[stage].empty())
+	if (!((ctx->prof_mask >> stage) & 1u) || ctx->prof[stage].empty())
 		return;
 	(void)hipEventRecord(ctx->prof[stage].back().b, ctx->stream);
 }
@@ -277,7 +277,9 @@ extern "C" int ugrt_prof_enable(ugrt_ctx *ctx, int on)
 {
 	if (!ctx)
 		return ugrt_fail(UGRT_EINVAL, "prof_enable: null ctx");
-	ctx->prof_on = on != 0;
+	// 0: off, 1: every stage, otherwise bit (s + 1) selects stage s (event pairs cost a few
+	// microseconds each, so a timed loop may want only the kernels it reports)
+	ctx->prof_mask = on == 0 ? 0u : (on == 1 ? 0xFFFFFFFFu : ((unsigned)on >> 1));
 	return UGRT_OK;
 }
 

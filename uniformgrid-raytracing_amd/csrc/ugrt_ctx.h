@@ -61,7 +61,7 @@ struct ugrt_ctx {
 	DevBuf tkey[2], tval[2], tbcnt;                      // shadow tracer: candidate pairs, runs per beam
 	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
 	u32 *d_small = nullptr;       // 16 u32 of device scratch (totals)
-	bool prof_on = false;
+	unsigned prof_mask = 0; // bit s = stage s is timed
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;
 	unsigned long long stats[8] = { 0 };

@@ -178,8 +178,15 @@ class Context:
         check(lib.ugrt_animate(self._h, _ptr(verts), _ptr(orig), size, offset, rot))
 
     # -- profiling -----------------------------------------------------------
-    def prof_enable(self, on=True):
-        check(lib.ugrt_prof_enable(self._h, 1 if on else 0))
+    def prof_enable(self, on=True, stages=None):
+        """stages: iterable of stage names to time (default: all)."""
+        if on and stages is not None:
+            mask = 0
+            for name in stages:
+                mask |= 1 << (STAGES.index(name) + 1)
+            check(lib.ugrt_prof_enable(self._h, mask))
+        else:
+            check(lib.ugrt_prof_enable(self._h, 1 if on else 0))
 
     def prof_reset(self):
         check(lib.ugrt_prof_reset(self._h))

@@ -43,9 +43,22 @@ def make_camera(params, fovy, aspect):
 
 
 class Renderer:
-    def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3):
+    def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False):
+        """overlap=True: the light grid and the uniform grid (which do not depend on the camera pass) are built
+        by a second context on a second HIP stream while the main stream builds the perspective grid and
+        traces the primary rays; streams are joined with events before the grids are consumed.  Same results."""
         t = ctx.torch
         self.ctx = ctx
+        self.aux = None
+        if overlap:
+            from .device import Context
+
+            self.main_stream = t.cuda.current_stream(ctx.device)
+            self.aux_stream = t.cuda.Stream(ctx.device)
+            with t.cuda.stream(self.aux_stream):
+                self.aux = Context(ctx.width, ctx.height, device=ctx.device_index, light_grid=ctx.light_grid,
+                                   rows=ctx.rows, flags=int(ctx.cfg.flags),
+                                   uniform_dims=tuple(ctx.cfg.uniform_dims[k] for k in range(3)))
         self.F = int(len(faces))
         self.num_materials = int(len(mat_list) // 6 if np.ndim(mat_list) == 1 else len(mat_list))
         self.d_verts = ctx.upload(np.asarray(verts, np.float32).reshape(-1))
@@ -92,6 +105,8 @@ class Renderer:
             self.hit_id = self.ctx.empty(self.N, t.int32)
 
     def display(self, setup, frame_cnt=1, shadows=True, reflect=False, shade=True):
+        if self.aux is not None and shade:
+            return self._display_overlapped(setup, frame_cnt, shadows, reflect)
         ctx = self.ctx
         t = ctx.torch
         # updateLightPosition, per_frame_funcs.h:6
@@ -137,6 +152,63 @@ class Renderer:
                                 self.d_matidx, self.d_matlist, self.num_materials)
         if shadows:
             ctx.shade_add_shadows(self.image, self.is_shadowed)
+
+    def _display_overlapped(self, setup, frame_cnt, shadows, reflect):
+        """display() with the camera-independent grid builds on the second stream."""
+        ctx, aux, t = self.ctx, self.aux, self.ctx.torch
+        main, side = self.main_stream, self.aux_stream
+        lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
+        # side stream: starts once the geometry of this frame is final on the main stream
+        side.wait_stream(main)
+        if shadows:
+            aux.upload_camera(lcam.camcoords)
+            aux.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
+        if reflect:
+            aux.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
+        # main stream: the camera pass
+        ctx.set_light_position(setup.shading_light)
+        cam = make_camera(setup.camera, setup.fovy, self.aspect)
+        self.cam_pos.copy_(t.from_numpy(cam.worldori[:3].copy()), non_blocking=False)
+        ctx.upload_camera(cam.camcoords)
+        ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
+        value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
+        ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed, self.intersect_id,
+                          self.d_verts, self.d_faces)
+        ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
+        if shadows:
+            ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
+            self.num_chunks = ctx.sort_rays(self.d_map, self.prefix)
+            main.wait_stream(side)  # light grid ready
+            lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
+            ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
+                             self.d_map, self.prefix, self.cam_pos, self.num_chunks)
+        if reflect:
+            self._ensure_reflect_buffers()
+            ctx.reflect_rays(self.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
+                             self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays,
+                             self.active)
+            # the traversal runs where the uniform grid's geometry lives
+            side.wait_stream(main)
+            uvalue, uspan, uoffset, _ = aux.grid_ptrs(GRID_UNIFORM)
+            aux.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active, self.hit_t,
+                          self.hit_id)
+            main.wait_stream(side)
+            ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                              self.d_matidx, self.d_matlist, self.d_reflect, self.num_materials, self.d_verts,
+                              self.d_faces, self.rays, self.active, self.hit_t, self.hit_id)
+        elif frame_cnt < 2:
+            ctx.shade_simple(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                             self.d_matidx, self.d_matlist, self.num_materials)
+        else:
+            ctx.shade_spotlight(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                                self.d_matidx, self.d_matlist, self.num_materials)
+        if shadows:
+            ctx.shade_add_shadows(self.image, self.is_shadowed)
+
+    def synchronize(self):
+        self.ctx.synchronize()
+        if self.aux is not None:
+            self.aux.synchronize()
 
     def band_image(self):
         """uint8 view [rows*8, W, 3] of this context's band."""

@@ -791,11 +791,10 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict_
 		pend[b] = i + 1;
 }
 
-#define XSEG 256u // candidates per exact-pass work item
 
 __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
 								 const GBox *__restrict__ boxes, u32 G, u32 *__restrict__ xcnt,
-								 unsigned long long *__restrict__ staged)
+								 unsigned long long *__restrict__ staged, u32 XSEG)
 {
 	u32 g = blockIdx.x * WL_THREADS + threadIdx.x;
 	unsigned long long mine = 0;
@@ -821,7 +820,7 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      const float4 *__restrict__ rec, const float *__restrict__ t_value_list,
 						      const float *__restrict__ ray_direction_list,
 						      int *__restrict__ is_shadowed, const u32 *__restrict__ ray_pixels,
-						      const float *__restrict__ cmPt)
+						      const float *__restrict__ cmPt, u32 XSEG)
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
 	const int lane = threadIdx.x;
@@ -991,6 +990,13 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if (const char *e = getenv("UGRT_SHADOW_BEAM"))
 		beam = (u32)atoi(e);
 	beam = beam < 64u ? 64u : (beam > 8192u ? 8192u : (beam + 63u) / 64u * 64u);
+	// candidates per exact-pass work item: a 64-ray sub-group stops at the first batch after which all its
+	// rays are flagged, so long items cost little where everything is in shadow; short items bound the
+	// work of a sub-group that stays lit
+	u32 XSEG = 128u;
+	if (const char *e = getenv("UGRT_SHADOW_XSEG"))
+		XSEG = (u32)atoi(e);
+	XSEG = XSEG < 64u ? 64u : (XSEG + 63u) / 64u * 64u;
 	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
 			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt, beam, wcnt);
 	UGRT_HIP(hipGetLastError());
@@ -1064,7 +1070,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	UGRT_HIP(hipGetLastError());
 	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + G;
 	hipLaunchKernelGGL(k_pair_item_count, dim3((G + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt, wcnt + 1);
+			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt, wcnt + 1, XSEG);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, G)))
 		return rc;
@@ -1076,12 +1082,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for((G + P / XSEG) * (beam / 64u))), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
-				   (const u32 *)v1, d_cam_position);
+				   (const u32 *)v1, d_cam_position, XSEG);
 	else
 		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for((G + P / XSEG) * (beam / 64u))), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
-				   (const u32 *)v1, d_cam_position);
+				   (const u32 *)v1, d_cam_position, XSEG);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

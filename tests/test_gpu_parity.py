@@ -279,6 +279,112 @@ def test_split_cells_merge(ugrt, O, torch):
         assert_bits_equal(r.normal.cpu().numpy(), want["normal"], "normal")
 
 
+def _with_wide_triangles(s, cam, n_extra, seed=3):
+    """The scene plus (a) backdrop triangles larger than the view of `cam` (every screen cell) and (b) triangles between opposite corners of the scene box (every uniform cell),
+    interleaved with the scene's own triangles so that wide ids fall between narrow ids."""
+    rng = np.random.default_rng(seed)
+    verts, faces = s["verts"].astype(np.float32), s["faces"].astype(np.int32)
+    e, look, up = (np.array(cam[k], np.float64) for k in ("eye", "look", "up"))
+    f = (look - e) / np.linalg.norm(look - e)
+    rt = np.cross(f, up)
+    rt /= np.linalg.norm(rt)
+    u = np.cross(rt, f)
+    ext = []
+    for k in range(n_extra):
+        j = rng.uniform(0.8, 1.2, 6)
+        d = 30.0 + 3.0 * k / n_extra  # backdrops behind the scene, larger than the view
+        ext.append(np.stack([e + d * f - 100 * j[0] * rt - 100 * j[1] * u,
+                             e + d * f + 100 * j[2] * rt - 100 * j[3] * u,
+                             e + d * f + 10 * j[4] * rt + 100 * j[5] * u]))
+    both = np.concatenate([verts] + ext)
+    lo, hi = both.min(0), both.max(0)
+    for k in range(n_extra):
+        c = lo + (hi - lo) * rng.uniform(0.3, 0.7, 3)
+        ext.append(np.stack([lo, hi, c]))
+    ext = np.concatenate(ext).astype(np.float32)
+    v2 = np.concatenate([verts, ext])
+    extra_faces = (len(verts) + np.arange(len(ext), dtype=np.int32)).reshape(-1, 3)
+    pos = np.sort(rng.integers(0, len(faces) + 1, len(extra_faces)))
+    f2 = np.insert(faces, pos, extra_faces, axis=0).astype(np.int32)
+    m2 = np.insert(s["matidx"].astype(np.int32), pos, 0)
+    out = dict(s)
+    out.update(verts=v2, faces=f2, matidx=m2)
+    return out
+
+
+@pytest.mark.parametrize("n_extra", [1, 7, 200])
+def test_wide_triangles_are_merged_not_sorted(ugrt, O, torch, n_extra):
+    """Triangles whose range is the whole grid bypass fill + sort and are merged into every cell's run:
+    the lists must equal the oracle's sort of ALL references, for the screen grid, a band of it and the
+    uniform grid; the frame on top of them must not change either."""
+    s = scene(ugrt, "cornell")
+    cam = s["cameras"]["B"]
+    s = _with_wide_triangles(s, cam, n_extra)
+    W, H, lg, ud = 128, 96, (32, 32), (8, 8, 4)
+    for rows in (None, (3, 9)):
+        ctx, r = make(ugrt, s, W, H, lg, rows=rows, udims=ud)
+        ocam = O.cam_from(cam, 45.0, r.aspect)
+        g = O.grid_perspective(ocam.cc, s["faces"], s["verts"], W // 8, H // 8, rows=rows)
+        ncell_active = (W // 8) * ((rows[1] - rows[0]) if rows else H // 8)
+        assert (np.bincount(g["vals"]) == ncell_active).sum() >= n_extra
+        for _ in range(2):
+            ctx.upload_camera(ocam.cc)
+            ctx.grid_build_perspective(r.d_faces, r.d_verts, r.F)
+            ctx.synchronize()
+            value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
+            assert gi.total_refs == g["R"] and gi.cells_used == g["used"]
+            np.testing.assert_array_equal(u32(key), g["keys"])
+            np.testing.assert_array_equal(u32(value), g["vals"])
+            np.testing.assert_array_equal(u32(span), g["span"])
+            np.testing.assert_array_equal(u32(offset), g["offset"])
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    setup = ugrt.FrameSetup(cam, s["light_camera"], s["shading_light"])
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud)
+    for which, og in ((ugrt.GRID_UNIFORM, want["ugrid"]), (ugrt.GRID_SPHERICAL, want["lgrid"])):
+        value, key, span, offset, gi = ctx.grid_arrays(which)
+        assert gi.total_refs == og["R"]
+        np.testing.assert_array_equal(u32(key), og["keys"])
+        np.testing.assert_array_equal(u32(value), og["vals"])
+        np.testing.assert_array_equal(u32(span), og["span"])
+    ncell = ud[0] * ud[1] * ud[2]
+    assert (np.bincount(want["ugrid"]["vals"]) == ncell).sum() >= n_extra
+    np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"])
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"])
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+
+
+def test_many_wide_triangles_tiny_grid(ugrt, O, torch):
+    """More than 4096 wide triangles (a 2-cell screen grid): the id list goes through the radix sort."""
+    rng = np.random.default_rng(11)
+    n = 6000
+    tri = np.zeros((n, 3, 3))
+    tri[:, 0] = np.c_[rng.uniform(-1.5, -0.2, n), rng.uniform(-0.4, 0.4, n), rng.uniform(-6, -4, n)]
+    tri[:, 1] = np.c_[rng.uniform(0.2, 1.5, n), rng.uniform(-0.4, 0.4, n), rng.uniform(-6, -4, n)]
+    tri[:, 2] = np.c_[rng.uniform(-1.5, 1.5, n), rng.uniform(-0.4, 0.4, n), rng.uniform(-6, -4, n)]
+    tri[::5, 1, 0] = -0.1  # every fifth stays in the left cell
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    faces = np.arange(len(verts)).reshape(-1, 3).astype(np.int32)
+    s = dict(verts=verts, faces=faces, matidx=np.zeros(len(faces), np.int32),
+             mat_list=np.array([[0.2, 0.2, 0.2, 0.8, 0.8, 0.8]], np.float32), reflect=np.zeros(1, np.float32))
+    cam = dict(eye=(0, 0, 0), look=(0, 0, -1), up=(0, 1, 0), near=0.1, far=100.0)
+    W, H = 16, 8
+    ctx, r = make(ugrt, s, W, H, (16, 16))
+    ocam = O.cam_from(cam, 45.0, r.aspect)
+    g = O.grid_perspective(ocam.cc, faces, verts, 2, 1)
+    assert (np.bincount(g["vals"]) == 2).sum() > 4096 and (np.bincount(g["vals"]) == 1).sum() > 500
+    ctx.upload_camera(ocam.cc)
+    ctx.grid_build_perspective(r.d_faces, r.d_verts, r.F)
+    ctx.synchronize()
+    value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
+    assert gi.total_refs == g["R"] and gi.cells_used == g["used"]
+    np.testing.assert_array_equal(u32(key), g["keys"])
+    np.testing.assert_array_equal(u32(value), g["vals"])
+    np.testing.assert_array_equal(u32(span), g["span"])
+    np.testing.assert_array_equal(u32(offset), g["offset"])
+
+
 def test_known_answers_on_gpu(ugrt, torch):
     """centre tile, one triangle at z=-5 -> 64/64 hits, t=5, n=(0,0,1), dir=(0,0,-1), id 0."""
     verts = np.array([[-50, -50, -5], [50, -50, -5], [0, 50, -5]], np.float32)

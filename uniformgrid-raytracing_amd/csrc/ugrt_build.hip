@@ -9,6 +9,11 @@
 //   rocPRIM radix sort on ceil(log2 C) bits -> one boundary kernel -> one
 //   per-cell kernel -> rocPRIM exclusive scan.  Outputs are identical arrays:
 //   value[R], key[R], span[C], offset[C].
+// Triangles whose cell range is the WHOLE grid (the reference clamps the screen box of a triangle that
+//   straddles the eye plane to the full screen, SURVEY.md Q9: 325 of 1 M triangles make 10.3 M of the
+//   12.2 M references of the bench scene) are not pushed through fill + sort: they are kept as a short
+//   sorted id list and merged into every cell's run after the sort of the remaining references.  The
+//   output arrays are the same, element for element.
 // With NUM_SLABS = 1 the z-slab stage (SlabKernel, grid_kernel.cu:334, and the
 // host zMin/zMax loop, frustum_grid.h:221-241) always yields slab 0 and is
 // dropped.
@@ -26,9 +31,11 @@ struct Rng {
 // done once per build instead of once per (cell, triangle) reference.
 __global__ __launch_bounds__(BUILD_THREADS) void k_tri_records(const int *__restrict__ faces,
 								const float *__restrict__ verts, int F,
-								float4 *__restrict__ rec)
+								float4 *__restrict__ rec, u32 *__restrict__ wcount)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (f == 0)
+		*wcount = 0; // the count kernel that follows appends the wide triangles
 	if (f >= F)
 		return;
 	int i1 = 3 * faces[f * 3 + 0], i2 = 3 * faces[f * 3 + 1], i3 = 3 * faces[f * 3 + 2];
@@ -40,15 +47,39 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_tri_records(const int *__rest
 	rec[f * 3 + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
 }
 
+// A triangle that covers all `full` active cells goes to the wide list and contributes no references
+// to fill + sort (one atomic per wave that holds any).
+__device__ __forceinline__ u32 d_split_wide(int f, u32 size, u32 full, u32 *__restrict__ wide,
+					     u32 *__restrict__ wcount)
+{
+	const bool w = size == full && full > 1u;
+	const unsigned long long mask = __ballot(w);
+	if (mask == 0ull)
+		return size;
+	const int leader = (int)__builtin_ctzll(mask);
+	const int lane = (int)(threadIdx.x & 63u);
+	u32 base = 0;
+	if (lane == leader)
+		base = atomicAdd(wcount, (u32)__popcll(mask));
+	base = __shfl(base, leader);
+	if (w) {
+		wide[base + (u32)__popcll(mask & ((1ull << lane) - 1ull))] = (u32)f;
+		return 0u;
+	}
+	return size;
+}
+
 // DSKernel, grid_kernel.cu:164-243 (+ the band clamp of the multi-GPU split)
 __global__ __launch_bounds__(BUILD_THREADS) void k_count_persp(CamBlock cam, const int *__restrict__ faces,
 								const float *__restrict__ verts, int F,
 								int gy_lo, int gy_hi, Rng *__restrict__ rng,
-								u32 *__restrict__ sizes)
+								u32 *__restrict__ sizes, u32 *__restrict__ wide,
+								u32 *__restrict__ wcount)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (f >= F)
-		return;
+		f = F - 1; // keeps the wave whole for d_split_wide; the duplicate is dropped below
+	const bool dup = (int)(blockIdx.x * BUILD_THREADS + threadIdx.x) >= F;
 	int i1 = 3 * faces[f * 3 + 0], i2 = 3 * faces[f * 3 + 1], i3 = 3 * faces[f * 3 + 2];
 	float v1[3], v2[3], v3[3];
 	d_transformed_vertex(cam, verts[i1], verts[i1 + 1], verts[i1 + 2], v1);
@@ -77,6 +108,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_persp(CamBlock cam, con
 	r.x = (u32)gxmin | ((u32)gxmax << 16);
 	r.y = (u32)gymin | ((u32)gymax << 16);
 	r.z = 0;
+	size = d_split_wide(f, dup ? 0u : size, (u32)(nbx * (gy_hi - gy_lo)), wide, wcount);
+	if (dup)
+		return;
 	rng[f] = r;
 	sizes[f] = size;
 }
@@ -85,11 +119,13 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_persp(CamBlock cam, con
 __global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const int *__restrict__ faces,
 							      const float *__restrict__ verts, int F, int lnbx,
 							      int lnby, float xM, float yM, Rng *__restrict__ rng,
-							      u32 *__restrict__ sizes)
+							      u32 *__restrict__ sizes, u32 *__restrict__ wide,
+							      u32 *__restrict__ wcount)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (f >= F)
-		return;
+		f = F - 1;
+	const bool dup = (int)(blockIdx.x * BUILD_THREADS + threadIdx.x) >= F;
 	int blx[3], bly[3];
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
@@ -113,8 +149,12 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const
 	r.x = (u32)gxmin | ((u32)gxmax << 16);
 	r.y = (u32)gymin | ((u32)gymax << 16);
 	r.z = 0;
+	u32 size = (u32)((gxmax - gxmin + 1) * (gymax - gymin + 1));
+	size = d_split_wide(f, dup ? 0u : size, (u32)(lnbx * lnby), wide, wcount);
+	if (dup)
+		return;
 	rng[f] = r;
-	sizes[f] = (u32)((gxmax - gxmin + 1) * (gymax - gymin + 1));
+	sizes[f] = size;
 }
 
 struct UGrid {
@@ -131,11 +171,13 @@ __device__ __forceinline__ int d_ucell(const UGrid &g, int k, float p)
 // uniform grid: world-space bbox -> 3-D cell range
 __global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const int *__restrict__ faces,
 								  const float *__restrict__ verts, int F,
-								  Rng *__restrict__ rng, u32 *__restrict__ sizes)
+								  Rng *__restrict__ rng, u32 *__restrict__ sizes,
+								  u32 *__restrict__ wide, u32 *__restrict__ wcount)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (f >= F)
-		return;
+		f = F - 1;
+	const bool dup = (int)(blockIdx.x * BUILD_THREADS + threadIdx.x) >= F;
 	int i1 = 3 * faces[f * 3 + 0], i2 = 3 * faces[f * 3 + 1], i3 = 3 * faces[f * 3 + 2];
 	u32 packed[3], size = 1;
 #pragma unroll
@@ -150,6 +192,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const 
 	r.x = packed[0];
 	r.y = packed[1];
 	r.z = packed[2];
+	size = d_split_wide(f, dup ? 0u : size, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], wide, wcount);
+	if (dup)
+		return;
 	rng[f] = r;
 	sizes[f] = size;
 }
@@ -209,18 +254,125 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_bounds(const u32 *__restrict_
 
 // span = run length (0 for cells without a run: set_as_zero, misc_kernel.cu:26); also counts the
 // occupied cells ("Number of actual cells", frustum_grid.h:337) with one atomic per block
+// A cell is "active" when its y index lies in [ylo, yhi] (the whole grid, or this rank's band of the
+// screen grid); every active cell also holds the W wide triangles.
+struct WideBox {
+	u32 W, ny, nz, ylo, yhi;
+};
+
+__device__ __forceinline__ bool d_cell_active(const WideBox &wb, u32 c)
+{
+	u32 y = (c / wb.nz) % wb.ny;
+	return y >= wb.ylo && y <= wb.yhi;
+}
+
 __global__ __launch_bounds__(BUILD_THREADS) void k_span(const u32 *__restrict__ cstart, u32 *__restrict__ span_io,
-							 u32 C, u32 *__restrict__ used)
+							 u32 C, u32 *__restrict__ used, WideBox wb)
 {
 	u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	u32 sp = 0;
 	if (c < C) {
 		sp = span_io[c] - cstart[c]; // span_io holds the run end on entry
+		if (wb.W && d_cell_active(wb, c))
+			sp += wb.W;
 		span_io[c] = sp;
 	}
 	int cnt = __syncthreads_count(sp != 0);
 	if (threadIdx.x == 0 && cnt)
 		atomicAdd(used, (u32)cnt);
+}
+
+// ascending order of the (few) wide triangle ids: rank = number of smaller ids
+__global__ __launch_bounds__(BUILD_THREADS) void k_wide_rank(const u32 *__restrict__ wl, u32 W,
+							      u32 *__restrict__ sorted)
+{
+	u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (i >= W)
+		return;
+	u32 v = wl[i], r = 0;
+	for (u32 j = 0; j < W; j++)
+		r += wl[j] < v ? 1u : 0u;
+	sorted[r] = v;
+}
+
+// number of elements of the ascending list a[0..n) that are smaller than v; the trip count depends on n
+// only (uniform across the wave), pow2 = smallest power of two >= n
+template <typename P>
+__device__ __forceinline__ u32 d_lower_bound(P a, u32 n, u32 pow2, u32 v)
+{
+	u32 pos = 0;
+	for (u32 step = pow2; step; step >>= 1) {
+		u32 t = pos + step;
+		if (t <= n && a[t - 1] < v)
+			pos = t;
+	}
+	return pos;
+}
+
+__device__ __forceinline__ u32 d_pow2_ge(u32 n)
+{
+	return n <= 1u ? n : 1u << (32 - __builtin_clz(n - 1u));
+}
+
+// Merge of the sorted narrow references with the sorted wide list.  Within a cell both are ascending id
+// lists without common elements: element i of one lands at i + (smaller elements of the other).
+// Narrow side: one thread per reference (a cell may hold thousands).
+#define MERGE_LDS 1024
+__global__ __launch_bounds__(BUILD_THREADS) void k_merge_narrow(const u32 *__restrict__ nkeys,
+								 const u32 *__restrict__ nvals, u32 Rn,
+								 const u32 *__restrict__ cstart,
+								 const u32 *__restrict__ offset,
+								 const u32 *__restrict__ wl, WideBox wb,
+								 u32 *__restrict__ okeys, u32 *__restrict__ ovals)
+{
+	__shared__ u32 s_w[MERGE_LDS];
+	const bool w_lds = wb.W <= MERGE_LDS;
+	if (w_lds)
+		for (u32 k = threadIdx.x; k < wb.W; k += BUILD_THREADS)
+			s_w[k] = wl[k];
+	__syncthreads();
+	const u32 j = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (j >= Rn)
+		return;
+	const u32 c = nkeys[j], id = nvals[j];
+	const u32 wp2 = d_pow2_ge(wb.W);
+	u32 lb = 0;
+	if (d_cell_active(wb, c))
+		lb = w_lds ? d_lower_bound(s_w, wb.W, wp2, id) : d_lower_bound(wl, wb.W, wp2, id);
+	const u32 pos = offset[c] + (j - cstart[c]) + lb;
+	ovals[pos] = id;
+	okeys[pos] = c;
+}
+
+// Wide side: one wave per active cell, the cell's narrow run is searched in LDS when it fits.
+__global__ __launch_bounds__(64) void k_merge_wide(const u32 *__restrict__ nvals, const u32 *__restrict__ cstart,
+						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
+						    const u32 *__restrict__ wl, u32 C, WideBox wb,
+						    u32 *__restrict__ okeys, u32 *__restrict__ ovals)
+{
+	__shared__ u32 s_n[MERGE_LDS];
+	const u32 lane = threadIdx.x;
+	for (u32 c = blockIdx.x; c < C; c += gridDim.x) {
+		if (!d_cell_active(wb, c))
+			continue;
+		const u32 ns = span[c] - wb.W;
+		const u32 *nv = nvals + cstart[c];
+		const u32 out = offset[c];
+		const bool n_lds = ns <= MERGE_LDS;
+		const u32 np2 = d_pow2_ge(ns);
+		__syncthreads(); // the previous cell's s_n is no longer read
+		if (n_lds)
+			for (u32 i = lane; i < ns; i += 64u)
+				s_n[i] = nv[i];
+		__syncthreads();
+		for (u32 k = lane; k < wb.W; k += 64u) {
+			const u32 id = wl[k];
+			const u32 lb = n_lds ? d_lower_bound(s_n, ns, np2, id) : d_lower_bound(nv, ns, np2, id);
+			const u32 pos = out + k + lb;
+			ovals[pos] = id;
+			okeys[pos] = c;
+		}
+	}
 }
 
 static int bits_for(u32 C)
@@ -231,8 +383,9 @@ static int bits_for(u32 C)
 	return b;
 }
 
-// shared tail of the three builders: sizes/rng are filled, ny/nz give the key layout
-static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz)
+// shared tail of the three builders: sizes/rng/wide list are filled, ny/nz give the key layout,
+// [ylo, yhi] the y range of the cells a wide triangle covers
+static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, int ylo, int yhi)
 {
 	hipStream_t st = ctx->stream;
 	int rc;
@@ -245,52 +398,96 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz)
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_SCAN);
 	if (rc)
 		return rc;
-	// total_triangles, frustum_grid.h:254 (the one unavoidable read-back: it sizes the lists)
+	// total_triangles, frustum_grid.h:254 (the one unavoidable read-back: it sizes the lists), here
+	// as narrow references + number of wide triangles
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned, (u32 *)G.scan.p + (F - 1), 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 1, ugrt_wide_counter(ctx), 4, hipMemcpyDeviceToHost, st));
 	UGRT_HIP(hipStreamSynchronize(st));
-	u32 R = ctx->h_pinned[0];
+	const u32 Rn = ctx->h_pinned[0], W = ctx->h_pinned[1];
+	WideBox wb;
+	wb.W = W;
+	wb.ny = (u32)ny;
+	wb.nz = (u32)nz;
+	wb.ylo = (u32)ylo;
+	wb.yhi = (u32)yhi;
+	const unsigned long long active = (unsigned long long)(C / ((u32)ny * (u32)nz)) * (u32)(yhi - ylo + 1) * (u32)nz;
+	const unsigned long long Rtot = (unsigned long long)Rn + active * W;
+	if (Rtot > 0xFFFFFFF0ull)
+		return ugrt_fail(UGRT_ENOMEM, "grid build: %llu references exceed the 32-bit lists", Rtot);
+	const u32 R = (u32)Rtot;
 	G.R = R;
-	size_t rb = (size_t)(R ? R : 1) * 4;
-	for (int i = 0; i < 2; i++) {
-		if ((rc = ugrt_buf_reserve(ctx, G.key[i], rb)))
-			return rc;
-		if ((rc = ugrt_buf_reserve(ctx, G.val[i], rb)))
-			return rc;
-	}
+	// the sort goes key[0] -> key[1]; with wide triangles the merged lists are written back into key[0]
+	size_t rb1 = (size_t)(Rn ? Rn : 1) * 4, rb0 = W ? (size_t)(R ? R : 1) * 4 : rb1;
+	if ((rc = ugrt_buf_reserve(ctx, G.key[0], rb0)) || (rc = ugrt_buf_reserve(ctx, G.val[0], rb0)) ||
+	    (rc = ugrt_buf_reserve(ctx, G.key[1], rb1)) || (rc = ugrt_buf_reserve(ctx, G.val[1], rb1)))
+		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 8 + 16))) // span[C], run starts[C], cells_used
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.offset, (size_t)C * 4)))
 		return rc;
 	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
-	if (R) {
+	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
+	if (Rn) {
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
-		hipLaunchKernelGGL(k_fill, dim3((R + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)G.scan.p, (const Rng *)G.rng.p, F, R, ny, nz, k0, v0);
+		hipLaunchKernelGGL(k_fill, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   (const u32 *)G.scan.p, (const Rng *)G.rng.p, F, Rn, ny, nz, k0, v0);
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-		rc = ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, R, bits_for(C));
+		rc = ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, Rn, bits_for(C));
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 		if (rc)
 			return rc;
 	}
-	G.keys = k1;
-	G.vals = v1;
+	if (W) {
+		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
+		if (W <= 4096u) {
+			hipLaunchKernelGGL(k_wide_rank, dim3((W + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
+					   st, (const u32 *)wl, W, wsorted);
+			UGRT_HIP(hipGetLastError());
+		} else {
+			// many wide triangles (a tiny grid): radix sort of the ids, the values are not used
+			if ((rc = ugrt_buf_reserve(ctx, G.scan, (size_t)F * 4)))
+				return rc;
+			if ((rc = ugrt_prim_sort_pairs(ctx, wl, wsorted, wl, (u32 *)G.scan.p, W, bits_for((u32)F))))
+				return rc;
+		}
+		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
+	}
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
 	u32 *cstart = (u32 *)G.span.p + C, *used = cstart + C;
 	UGRT_HIP(hipMemsetAsync(G.span.p, 0, (size_t)C * 8 + 4, st)); // one fill for all three
 	if (R) {
-		hipLaunchKernelGGL(k_bounds, dim3((R + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)k1, R, cstart, (u32 *)G.span.p);
-		UGRT_HIP(hipGetLastError());
+		if (Rn) {
+			hipLaunchKernelGGL(k_bounds, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
+					   st, (const u32 *)k1, Rn, cstart, (u32 *)G.span.p);
+			UGRT_HIP(hipGetLastError());
+		}
 		hipLaunchKernelGGL(k_span, dim3((C + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)cstart, (u32 *)G.span.p, C, used);
+				   (const u32 *)cstart, (u32 *)G.span.p, C, used, wb);
 		UGRT_HIP(hipGetLastError());
 	}
 	rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C);
-	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
 	if (rc)
 		return rc;
+	if (W) {
+		if (Rn) {
+			hipLaunchKernelGGL(k_merge_narrow, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS),
+					   0, st, (const u32 *)k1, (const u32 *)v1, Rn, (const u32 *)cstart,
+					   (const u32 *)G.offset.p, (const u32 *)wsorted, wb, k0, v0);
+			UGRT_HIP(hipGetLastError());
+		}
+		u32 blocks = C < 256u * 32u ? C : 256u * 32u;
+		hipLaunchKernelGGL(k_merge_wide, dim3(blocks), dim3(64), 0, st, (const u32 *)v1, (const u32 *)cstart,
+				   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0);
+		UGRT_HIP(hipGetLastError());
+		G.keys = k0;
+		G.vals = v0;
+	} else {
+		G.keys = k1;
+		G.vals = v1;
+	}
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
 	// "Number of actual cells" (frustum_grid.h:337): fetched lazily by ugrt_grid_get_info
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + (&G - ctx->grid), used, 4, hipMemcpyDeviceToHost, st));
 	G.valid = true;
@@ -310,12 +507,14 @@ static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const f
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.sizes, (size_t)F * 4)))
 		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, G.wide, (size_t)F * 8))) // wide triangle ids as found, then ascending
+		return rc;
 	// the geometry may have changed since the last build (animation, a new frame file): refresh the records
 	ctx->rec_valid = false;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->trirec, (size_t)F * 48)))
 		return rc;
 	hipLaunchKernelGGL(k_tri_records, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
-			   ctx->stream, d_facelist, d_vertlist, F, (float4 *)ctx->trirec.p);
+			   ctx->stream, d_facelist, d_vertlist, F, (float4 *)ctx->trirec.p, ugrt_wide_counter(ctx));
 	UGRT_HIP(hipGetLastError());
 	ctx->rec_verts = d_vertlist;
 	ctx->rec_tris = d_facelist;
@@ -333,13 +532,14 @@ extern "C" int ugrt_grid_build_perspective(ugrt_ctx *ctx, const int *d_facelist,
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_persp, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, ctx->cfg.row_begin, ctx->cfg.row_end,
-			   (Rng *)G.rng.p, (u32 *)G.sizes.p);
+			   (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p, ugrt_wide_counter(ctx));
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
 	G.dims[0] = ctx->nbx;
 	G.dims[1] = ctx->nby;
 	G.dims[2] = 1;
-	return build_common(ctx, G, F, (u32)ctx->nbx * (u32)ctx->nby, ctx->nby, 1);
+	return build_common(ctx, G, F, (u32)ctx->nbx * (u32)ctx->nby, ctx->nby, 1, ctx->cfg.row_begin,
+			    ctx->cfg.row_end - 1);
 }
 
 // FrustumGrid::buildSphericalGrid, frustum_grid.h:368
@@ -354,13 +554,13 @@ extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, c
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_sph, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, lx, ly, xM, yM, (Rng *)G.rng.p,
-			   (u32 *)G.sizes.p);
+			   (u32 *)G.sizes.p, (u32 *)G.wide.p, ugrt_wide_counter(ctx));
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
 	G.dims[0] = lx;
 	G.dims[1] = ly;
 	G.dims[2] = 1;
-	return build_common(ctx, G, F, (u32)lx * (u32)ly, ly, 1);
+	return build_common(ctx, G, F, (u32)lx * (u32)ly, ly, 1, 0, ly - 1);
 }
 
 // uniform grid over the scene box (Model::{x,y,z}{Min,Max}, scene.h:273-292),
@@ -391,8 +591,10 @@ extern "C" int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, con
 	}
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_uniform, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
-			   ctx->stream, g, d_facelist, d_vertlist, F, (Rng *)G.rng.p, (u32 *)G.sizes.p);
+			   ctx->stream, g, d_facelist, d_vertlist, F, (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p,
+			   ugrt_wide_counter(ctx));
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
-	return build_common(ctx, G, F, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], g.dims[1], g.dims[2]);
+	return build_common(ctx, G, F, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], g.dims[1], g.dims[2], 0,
+			    g.dims[1] - 1);
 }

@@ -25,6 +25,7 @@ struct DevBuf {
 
 struct Grid {
 	DevBuf rng, sizes, scan;          // per triangle
+	DevBuf wide;                      // ids of the triangles that cover every cell: [F] as found, [F] ascending
 	DevBuf key[2], val[2];            // per ref, ping-pong for the radix sort
 	DevBuf span, offset;              // per cell (span buffer also holds run starts + cells_used)
 	u32 *keys = nullptr, *vals = nullptr; // sorted result (one of key[i]/val[i])
@@ -77,6 +78,7 @@ struct ugrt_ctx {
 
 int ugrt_buf_reserve(ugrt_ctx *ctx, DevBuf &b, size_t bytes);
 float *ugrt_ctx_tex(ugrt_ctx *ctx); // device copy of the 5x5x4 direction table
+static inline u32 *ugrt_wide_counter(ugrt_ctx *ctx) { return ctx->d_small + 3; } // wide triangles of the running build
 void ugrt_prof_begin(ugrt_ctx *ctx, int stage);
 void ugrt_prof_end(ugrt_ctx *ctx, int stage);
 

@@ -1127,27 +1127,44 @@ __device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long 
 // accepted hit is found with a 64-bit wave min on (t bits << 32 | r).  Sequentially the cell loop
 // keeps the first r with the smallest accepted t (strict <), which is exactly that minimum.
 // default results for every pixel + the list of active secondary rays (order is irrelevant)
+// Each wave owns DDA_PREP_SPAN consecutive pixels and reserves its slots with ONE atomic (a counter
+// bumped once per 64 pixels serialises ~30 k same-address atomics, 0.08 ms at 1080p).
+#define DDA_PREP_SPAN 512
 __global__ __launch_bounds__(256) void k_dda_prepare(const int *__restrict__ active, int p0, int npix,
 						      float *__restrict__ hit_t, int *__restrict__ hit_id,
 						      u32 *__restrict__ list, u32 *__restrict__ count)
 {
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	bool a = false;
-	int p = 0;
-	if (i < npix) {
-		p = p0 + i;
-		a = active[p] != 0;
-		hit_t[p] = -1.0f;
-		hit_id[p] = -2;
+	const int lane = threadIdx.x & 63;
+	const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DDA_PREP_SPAN;
+	if (first >= npix)
+		return;
+	u32 total = 0;
+	unsigned long long flags = 0ull; // bit k: this lane's pixel of round k is active
+#pragma unroll
+	for (int k = 0; k < DDA_PREP_SPAN / 64; k++) {
+		const int i = first + k * 64 + lane;
+		bool a = false;
+		if (i < npix) {
+			a = active[p0 + i] != 0;
+			hit_t[p0 + i] = -1.0f;
+			hit_id[p0 + i] = -2;
+		}
+		flags |= (unsigned long long)a << k;
+		total += (u32)__popcll(__ballot(a));
 	}
-	const unsigned long long mask = __ballot(a);
-	if (mask != 0ull) {
-		u32 base = 0;
-		if ((threadIdx.x & 63) == (u32)__builtin_ctzll(mask))
-			base = atomicAdd(count, (u32)__popcll(mask));
-		base = __shfl(base, (int)__builtin_ctzll(mask));
+	if (total == 0)
+		return;
+	u32 base = 0;
+	if (lane == 0)
+		base = atomicAdd(count, total);
+	base = __shfl(base, 0);
+#pragma unroll
+	for (int k = 0; k < DDA_PREP_SPAN / 64; k++) {
+		const bool a = (flags >> k) & 1ull;
+		const unsigned long long mask = __ballot(a);
 		if (a)
-			list[base + d_rank_in_mask(mask)] = (u32)p;
+			list[base + d_rank_in_mask(mask)] = (u32)(p0 + first + k * 64 + lane);
+		base += (u32)__popcll(mask);
 	}
 }
 
@@ -1374,7 +1391,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	if (!counting)
 		ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipMemsetAsync(dcount, 0, 4, ctx->stream));
-	hipLaunchKernelGGL(k_dda_prepare, dim3((ctx->npix + 255) / 256), dim3(256), 0, ctx->stream, d_active, ctx->p0,
+	hipLaunchKernelGGL(k_dda_prepare, dim3((ctx->npix + 4 * DDA_PREP_SPAN - 1) / (4 * DDA_PREP_SPAN)), dim3(256), 0, ctx->stream, d_active, ctx->p0,
 			   ctx->npix, d_hit_t, d_hit_id, list, dcount);
 	if (!counting) {
 		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);

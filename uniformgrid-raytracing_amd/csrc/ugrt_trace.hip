@@ -689,7 +689,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 						    const u32 *__restrict__ value_list, const float4 *__restrict__ rec,
 						    const float *__restrict__ verts, const int *__restrict__ tris,
 						    const GBox *__restrict__ boxes, u32 *__restrict__ pair_count, u32 pair_cap,
-						    u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri)
+						    u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri, u32 sbits)
 {
 	// candidate pairs are staged in LDS and flushed PAIR_BUF at a time: one atomic on the shared
 	// output cursor per ~450 pairs instead of one per beam iteration
@@ -713,6 +713,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 		u32 face = 0;
 		float nA[3] = { 0, 0, 0 }, nB[3] = { 0, 0, 0 }, nD[3] = { 0, 0, 0 }, nC[3] = { 0, 0, 0 };
 		float mA = 0.0f, mB = 0.0f, mD = 0.0f;
+		u32 code = 0;
 		if (have) {
 			face = value_list[offset[c] + first + lane];
 			float t9[9];
@@ -731,6 +732,11 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 			mA = fmaxf(K * a * cc, 1e-25f);
 			mB = fmaxf(K * a * b, 1e-25f);
 			mD = fmaxf(K * b * cc, 1e-25f);
+			// apparent size from the light, large first: the exact pass stops a ray at its first occluder
+			const float sa = __builtin_sqrtf(D_DOT(nD, nD)) / (D_DOT(tv, tv) + 1e-30f);
+			float lc = (__log2f(sa + 1e-30f) + 30.0f) * 5.0f;
+			lc = lc < 0.0f ? 0.0f : (lc > 255.0f ? 255.0f : lc);
+			code = (255u - (u32)lc) >> (8u - sbits);
 		}
 		const float mC = mA + mB + mD;
 		const u32 g0 = q * GCHUNK;
@@ -763,7 +769,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 			if (mask != 0ull) {
 				if (keep) {
 					const u32 pos = nbuf + d_rank_in_mask(mask);
-					buf_beam[pos] = gbase + g;
+					buf_beam[pos] = ((gbase + g) << sbits) | code;
 					buf_tri[pos] = face;
 				}
 				nbuf += (u32)__popcll(mask);
@@ -778,20 +784,23 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 		d_flush_pairs(buf_beam, buf_tri, nbuf, lane, pair_count, pair_cap, pair_beam, pair_tri);
 }
 
-__global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict__ beam, u32 P, u32 *__restrict__ pstart,
-							   u32 *__restrict__ pend)
+__global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict__ beam, u32 P, u32 sbits,
+							   u32 *__restrict__ pstart, u32 *__restrict__ pend)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (i >= P)
 		return;
-	u32 b = beam[i];
-	if (i == 0 || beam[i - 1] != b)
+	u32 b = beam[i] >> sbits;
+	if (i == 0 || (beam[i - 1] >> sbits) != b)
 		pstart[b] = i;
-	if (i == P - 1 || beam[i + 1] != b)
+	if (i == P - 1 || (beam[i + 1] >> sbits) != b)
 		pend[b] = i + 1;
 }
 
 
+// an item with segment number XSEG_LAST takes all the remaining candidates of its beam (the segment is
+// the 8-bit sort key of the item list; XSEG_LAST + 1 marks the padding behind the last item)
+#define XSEG_LAST 254u
 __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
 								 const GBox *__restrict__ boxes, u32 G, u32 *__restrict__ xcnt,
 								 unsigned long long *__restrict__ staged, u32 XSEG)
@@ -800,7 +809,8 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__res
 	unsigned long long mine = 0;
 	if (g < G) {
 		const u32 cand = pend[g] - pstart[g], nsub = (boxes[g].ray_count + 63u) / 64u;
-		xcnt[g] = ((cand + XSEG - 1) / XSEG) * nsub;
+		const u32 nseg = (cand + XSEG - 1) / XSEG;
+		xcnt[g] = (nseg < XSEG_LAST + 1u ? nseg : XSEG_LAST + 1u) * nsub;
 		mine = (unsigned long long)cand * nsub;
 	}
 	// candidates staged by the exact pass (work accounting): one atomic per wave
@@ -811,9 +821,36 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__res
 		atomicAdd(staged, mine);
 }
 
-// EXACT pass: item -> (beam, segment of its candidate list); lane = ray, the reference's test
+// The exact-pass items, listed once (the tracer then starts with two loads instead of a 12-step search)
+// and ordered by SEGMENT first: all beams' first segments run before any second segment, so by the time a
+// later segment of a beam is picked up its rays have mostly been flagged by the earlier ones and the item
+// ends at its first ballot.  key = segment, value = beam << 7 | sub-group.
+__global__ __launch_bounds__(WL_THREADS) void k_pair_items(const u32 *__restrict__ xincl, u32 G, u32 cap,
+							    const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
+							    const GBox *__restrict__ boxes, u32 XSEG,
+							    u32 *__restrict__ item_seg, u32 *__restrict__ item_sub)
+{
+	u32 it = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (it >= cap)
+		return;
+	if (it >= xincl[G - 1]) { // the list is sorted at its capacity: padding goes last
+		item_seg[it] = XSEG_LAST + 1u;
+		item_sub[it] = 0;
+		return;
+	}
+	const u32 g = d_find_cell(xincl, G, it);
+	u32 nseg = (pend[g] - pstart[g] + XSEG - 1) / XSEG;
+	nseg = nseg < XSEG_LAST + 1u ? nseg : XSEG_LAST + 1u;
+	const u32 nsub = (boxes[g].ray_count + 63u) / 64u;
+	const u32 local = it - (xincl[g] - nseg * nsub);
+	item_seg[it] = local / nsub;
+	item_sub[it] = (g << 7) | (local % nsub);
+}
+
+// EXACT pass: item -> (beam, segment of its candidate list, 64-ray sub-group); lane = ray, the reference's test
 template <bool REC>
 __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__restrict__ xincl, u32 G,
+						      const u32 *__restrict__ item_seg, const u32 *__restrict__ item_sub,
 						      const GBox *__restrict__ boxes, const u32 *__restrict__ pstart,
 						      const u32 *__restrict__ pend, const u32 *__restrict__ pair_tri,
 						      const float *__restrict__ verts, const int *__restrict__ tris,
@@ -828,14 +865,11 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
 	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
 	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
-		const u32 g = d_find_cell(xincl, G, it);
+		const u32 sgm = item_seg[it], gs = item_sub[it];
+		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list
 		const GBox bx = boxes[g];
-		const u32 nseg = (pend[g] - pstart[g] + XSEG - 1) / XSEG;
-		const u32 nsub = (bx.ray_count + 63u) / 64u;
-		const u32 local = it - (xincl[g] - nseg * nsub);
-		const u32 sgm = local / nsub, sub = local % nsub; // the sub-groups of a beam share its candidate list
 		const u32 p0 = pstart[g] + sgm * XSEG;
-		const u32 p1 = (p0 + XSEG) < pend[g] ? (p0 + XSEG) : pend[g];
+		const u32 p1 = (sgm != XSEG_LAST && (p0 + XSEG) < pend[g]) ? (p0 + XSEG) : pend[g];
 		const bool have_ray = 64u * sub + (u32)lane < bx.ray_count;
 		ShadowRay r;
 		r.rd[0] = r.rd[1] = r.rd[2] = 0.0f;
@@ -993,7 +1027,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// candidates per exact-pass work item: a 64-ray sub-group stops at the first batch after which all its
 	// rays are flagged, so long items cost little where everything is in shadow; short items bound the
 	// work of a sub-group that stays lit
-	u32 XSEG = 128u;
+	u32 XSEG = 256u;
 	if (const char *e = getenv("UGRT_SHADOW_XSEG"))
 		XSEG = (u32)atoi(e);
 	XSEG = XSEG < 64u ? 64u : (XSEG + 63u) / 64u * 64u;
@@ -1009,6 +1043,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			   d_ray_dir, d_cam_position, boxes, beam);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
+	u32 sbits = 4u;
+	if (const char *e = getenv("UGRT_SHADOW_SIZEBITS"))
+		sbits = (u32)atoi(e);
+	sbits = sbits > 8u ? 8u : sbits;
 	// 2. cull pass -> (beam, triangle) candidate pairs; grows the pair buffer and repeats if it was too small
 	u32 *pcount = ctx->d_small + 1;
 	u32 P = 0;
@@ -1035,11 +1073,11 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		if (use_rec)
 			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
-					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p);
+					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits);
 		else
 			hipLaunchKernelGGL(k_shadow_cull<false>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
-					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p);
+					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits);
 		ugrt_prof_end(ctx, UGRT_ST_SHADOW_CULL);
 		UGRT_HIP(hipGetLastError());
 		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, pcount, 4, hipMemcpyDeviceToHost, st));
@@ -1062,11 +1100,11 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// 3. candidates by beam
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
-				       (u32 *)ctx->tval[1].p, P, bits_of(G))))
+				       (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits)))
 		return rc;
 	UGRT_HIP(hipMemsetAsync(pstart, 0, maxg * 8, st));
 	hipLaunchKernelGGL(k_pair_runs, dim3((P + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)ctx->tkey[1].p, P, pstart, pend);
+			   (const u32 *)ctx->tkey[1].p, P, sbits, pstart, pend);
 	UGRT_HIP(hipGetLastError());
 	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + G;
 	hipLaunchKernelGGL(k_pair_item_count, dim3((G + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
@@ -1074,18 +1112,36 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, G)))
 		return rc;
+	const u32 xcap = (G + P / XSEG) * (beam / 64u); // >= number of exact-pass items
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sitem, (size_t)xcap * 16)))
+		return rc;
+	u32 *iseg0 = (u32 *)ctx->sitem.p, *isub0 = iseg0 + xcap, *iseg1 = isub0 + xcap, *isub1 = iseg1 + xcap;
+	hipLaunchKernelGGL(k_pair_items, dim3((xcap + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   (const u32 *)xincl, G, xcap, (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, XSEG,
+			   iseg0, isub0);
+	UGRT_HIP(hipGetLastError());
+	bool item_sort = true;
+	if (const char *e = getenv("UGRT_SHADOW_ITEMSORT"))
+		item_sort = atoi(e) != 0;
+	if (item_sort) {
+		if ((rc = ugrt_prim_sort_pairs(ctx, iseg0, iseg1, isub0, isub1, xcap, 8)))
+			return rc;
+	} else {
+		iseg1 = iseg0;
+		isub1 = isub0;
+	}
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 14, wcnt, 16, hipMemcpyDeviceToHost, st)); // read by ugrt_stats_get
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	if (use_rec)
-		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for((G + P / XSEG) * (beam / 64u))), dim3(64), 0, st, ctx->cam,
-				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
+		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
+				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG);
 	else
-		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for((G + P / XSEG) * (beam / 64u))), dim3(64), 0, st, ctx->cam,
-				   (const u32 *)xincl, G, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
+		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
+				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);

@@ -265,10 +265,70 @@ __device__ __forceinline__ u32 d_rank_in_mask(unsigned long long mask)
 	return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
 }
 
+// The same test with the triangle's part hoisted (it is reused for several boxes) and the box given as
+// centre +- half width: f(d) = n.d ranges over n.c -+ sum_k |n_k| r_k.
+struct CullTri {
+	float nA[3], nB[3], nC[3], nD[3];
+	float mA, mB, mD;
+};
+struct CBox {
+	float c[3], r[3];
+};
+
+__device__ __forceinline__ CullTri d_cull_prep(const float *tv, const float *e1, const float *e2)
+{
+	CullTri t;
+	D_CROSS(t.nA, e2, tv);
+	D_CROSS(t.nB, tv, e1);
+	D_CROSS(t.nD, e2, e1);
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		t.nC[k] = t.nA[k] + t.nB[k] - t.nD[k];
+	const float a = fmaxf(fmaxf(fabsf(tv[0]), fabsf(tv[1])), fabsf(tv[2]));
+	const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
+	const float c = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
+	const float K = 6.0f / 65536.0f;
+	t.mA = fmaxf(K * a * c, 1e-25f);
+	t.mB = fmaxf(K * a * b, 1e-25f);
+	t.mD = fmaxf(K * b * c, 1e-25f);
+	return t;
+}
+
+__device__ __forceinline__ bool d_cull_cr(const CullTri &t, const CBox &bx)
+{
+	const float Dm = t.nD[0] * bx.c[0] + t.nD[1] * bx.c[1] + t.nD[2] * bx.c[2];
+	const float Dr = fabsf(t.nD[0]) * bx.r[0] + fabsf(t.nD[1]) * bx.r[1] + fabsf(t.nD[2]) * bx.r[2];
+	if (!(Dm + Dr < 1e15f && Dm - Dr > -1e15f))
+		return false;
+	const float Am = t.nA[0] * bx.c[0] + t.nA[1] * bx.c[1] + t.nA[2] * bx.c[2];
+	const float Ar = fabsf(t.nA[0]) * bx.r[0] + fabsf(t.nA[1]) * bx.r[1] + fabsf(t.nA[2]) * bx.r[2];
+	const float Bm = t.nB[0] * bx.c[0] + t.nB[1] * bx.c[1] + t.nB[2] * bx.c[2];
+	const float Br = fabsf(t.nB[0]) * bx.r[0] + fabsf(t.nB[1]) * bx.r[1] + fabsf(t.nB[2]) * bx.r[2];
+	const float Cm = t.nC[0] * bx.c[0] + t.nC[1] * bx.c[1] + t.nC[2] * bx.c[2];
+	const float Cr = fabsf(t.nC[0]) * bx.r[0] + fabsf(t.nC[1]) * bx.r[1] + fabsf(t.nC[2]) * bx.r[2];
+	const float mC = t.mA + t.mB + t.mD;
+	if (Dm - Dr > t.mD) // det > 0 for every direction of the box
+		return (Am + Ar < -t.mA) || (Bm + Br < -t.mB) || (Cm - Cr > mC);
+	if (Dm + Dr < -t.mD) // det < 0
+		return (Am - Ar > t.mA) || (Bm - Br > t.mB) || (Cm + Cr < -mC);
+	return false;
+}
+
+__device__ __forceinline__ float d_readlane(float v, int l)
+{
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 #define SURV_CAP 128 // survivors buffered in LDS before the per-lane tests run (flush at >= 64)
 
+// One wave per item = (8x8-pixel tile, segment of its cell list).  lane = triangle: cull against the
+// tile's direction box, then against the boxes of its four 4x4-pixel QUADRANTS; survivors go to LDS once
+// and their slot numbers into one list per quadrant.  lane = pixel: every lane walks the list of ITS
+// quadrant, so the 64 lanes test up to four different triangles at a time and a small triangle costs a
+// quarter of the lanes instead of the whole wave.  Lists keep the cell-list order, which the reference's
+// strict "<" needs (first of equal t wins).
 template <bool REC>
-__global__ __launch_bounds__(64) void k_trace_primary(CamBlock cam, const float *__restrict__ tex,
+__global__ __launch_bounds__(64, 5) void k_trace_primary(CamBlock cam, const float *__restrict__ tex,
 						       const WItem *__restrict__ items,
 						       const u32 *__restrict__ nitems_p,
 						       const u32 *__restrict__ value_list,
@@ -277,7 +337,9 @@ __global__ __launch_bounds__(64) void k_trace_primary(CamBlock cam, const float 
 						       u64 *__restrict__ best, int p0)
 {
 	__shared__ __attribute__((aligned(16))) float lds[SURV_CAP * TRI_STRIDE];
+	__shared__ unsigned short qlist[4][SURV_CAP];
 	const int lane = threadIdx.x;
+	const int myq = ((lane >> 2) & 1) | ((lane >> 4) & 2); // quadrant of this lane's pixel (col bit 2, row bit 2)
 	const u32 nitems = *nitems_p;
 	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
 	for (u32 it = d_xcd_block(); it < nitems; it += gridDim.x) {
@@ -287,45 +349,96 @@ __global__ __launch_bounds__(64) void k_trace_primary(CamBlock cam, const float 
 		const int pixelID = row * cam.W + col;
 		float dir[3];
 		d_ray_dir(cam, tex, col, row, dir);
-		const DirBox box = d_dir_box(dir, true);
+		// direction boxes: reduce inside the quadrants (lane bits 0,1,3,4), then across them (bits 2,5);
+		// centre and half width are formed per lane and read from one lane of each quadrant, so that
+		// the boxes live in scalar registers
+		CBox qb[4], tb;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			float lo = dir[k], hi = dir[k];
+#pragma unroll
+			for (int m = 1; m <= 16; m <<= 1) {
+				if (m == 4)
+					continue;
+				lo = fminf(lo, __shfl_xor(lo, m));
+				hi = fmaxf(hi, __shfl_xor(hi, m));
+			}
+			const float qc = 0.5f * (lo + hi);
+			const float qr = 0.5f * (hi - lo) * 1.0001f + 1e-6f; // far more than the rounding of c and r
+			lo = fminf(lo, __shfl_xor(lo, 4));
+			hi = fmaxf(hi, __shfl_xor(hi, 4));
+			lo = fminf(lo, __shfl_xor(lo, 32));
+			hi = fmaxf(hi, __shfl_xor(hi, 32));
+			tb.c[k] = d_readlane(0.5f * (lo + hi), 0);
+			tb.r[k] = d_readlane(0.5f * (hi - lo) * 1.0001f + 1e-6f, 0);
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int src = ((q & 1) << 2) | ((q & 2) << 4);
+				qb[q].c[k] = d_readlane(qc, src);
+				qb[q].r[k] = d_readlane(qr, src);
+			}
+		}
 		float oldt = 99999999.9f;
 		u32 ref = 0xFFFFFFFFu;
-		u32 nsurv = 0;
+		u32 nsurv = 0, qn[4] = { 0, 0, 0, 0 };
 		for (u32 b = 0; b < w.count || nsurv; b += 64) {
 			if (b < w.count) {
-				// lane = triangle: load, cull against the tile's direction box, keep survivors in list order
 				const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
 				bool keep = false;
 				float t9[9];
+				CullTri ct;
 				if ((u32)lane < cnt) {
 					d_load_triangle<REC>(rec, verts, tris, value_list[w.begin + b + lane], ex, ey, ez, t9);
-					keep = !d_cull(&t9[0], &t9[3], &t9[6], box);
+					ct = d_cull_prep(&t9[0], &t9[3], &t9[6]);
+					keep = !d_cull_cr(ct, tb);
 				}
-				const unsigned long long mask = __ballot(keep);
-				if (keep) {
-					float4 *dst = reinterpret_cast<float4 *>(&lds[(nsurv + d_rank_in_mask(mask)) * TRI_STRIDE]);
-					dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
-					dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
-					dst[2] = make_float4(t9[8], __uint_as_float(w.begin + b + lane), 0.0f, 0.0f);
+				if (__ballot(keep) != 0ull) {
+					u32 km = 0;
+					if (keep) {
+#pragma unroll
+						for (int q = 0; q < 4; q++)
+							km |= d_cull_cr(ct, qb[q]) ? 0u : (1u << q);
+					}
+					keep = km != 0u;
+					const unsigned long long mask = __ballot(keep);
+					const u32 slot = nsurv + d_rank_in_mask(mask);
+					if (keep) {
+						float4 *dst = reinterpret_cast<float4 *>(&lds[slot * TRI_STRIDE]);
+						dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
+						dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
+						dst[2] = make_float4(t9[8], __uint_as_float(w.begin + b + lane), 0.0f, 0.0f);
+					}
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const unsigned long long mq = __ballot((km >> q) & 1u);
+						if ((km >> q) & 1u)
+							qlist[q][qn[q] + d_rank_in_mask(mq)] = (unsigned short)slot;
+						qn[q] += (u32)__popcll(mq);
+					}
+					nsurv += (u32)__popcll(mask);
 				}
-				nsurv += (u32)__popcll(mask);
 				if (nsurv < 64u && b + 64 < w.count)
 					continue; // keep collecting
 			}
-			// lane = pixel: the exact per-ray test of the reference on the survivors
+			// lane = pixel: the exact per-ray test of the reference on the survivors of its quadrant
 			__syncthreads();
-			for (u32 k = 0; k < nsurv; k++) {
-				const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
-				const float4 a = src[0], c = src[1], e = src[2];
-				const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
-				const float v = d_intersect_tri_uv(tv, e1, e2, dir, oldt);
-				if (v != 0.0f) {
-					oldt = v;
-					ref = __float_as_uint(e.y);
+			const u32 mine = myq == 0 ? qn[0] : (myq == 1 ? qn[1] : (myq == 2 ? qn[2] : qn[3]));
+			const u32 longest = max(max(qn[0], qn[1]), max(qn[2], qn[3]));
+			for (u32 k = 0; k < longest; k++) {
+				if (k < mine) {
+					const float4 *src = reinterpret_cast<const float4 *>(&lds[(u32)qlist[myq][k] * TRI_STRIDE]);
+					const float4 a = src[0], c = src[1], e = src[2];
+					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
+					const float v = d_intersect_tri_uv(tv, e1, e2, dir, oldt);
+					if (v != 0.0f) {
+						oldt = v;
+						ref = __float_as_uint(e.y);
+					}
 				}
 			}
 			__syncthreads();
 			nsurv = 0;
+			qn[0] = qn[1] = qn[2] = qn[3] = 0;
 		}
 		if (!w.multi) {
 			d_finish_pixel(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris);
@@ -507,12 +620,47 @@ __device__ __forceinline__ u32 d_dir_morton(const float *unit)
 	return d_spread10(q[0]) | (d_spread10(q[1]) << 1) | (d_spread10(q[2]) << 2);
 }
 
+// bits 0..15 of v spread to the even bits
+__device__ __forceinline__ u32 d_spread16(u32 v)
+{
+	v &= 0xFFFFu;
+	v = (v | (v << 8)) & 0x00FF00FFu;
+	v = (v | (v << 4)) & 0x0F0F0F0Fu;
+	v = (v | (v << 2)) & 0x33333333u;
+	v = (v | (v << 1)) & 0x55555555u;
+	return v;
+}
+
+// Directions are points of a sphere: an octahedral map sends them to the unit square, whose Z curve
+// needs two thirds of the bits of the cube's for the same angular resolution.  nu + nv code bits.
+__device__ __forceinline__ u32 d_dir_oct(const float *unit, u32 nu, u32 nv)
+{
+	const float inv = 1.0f / (fabsf(unit[0]) + fabsf(unit[1]) + fabsf(unit[2]) + 1e-30f);
+	float x = unit[0] * inv, y = unit[1] * inv;
+	if (unit[2] < 0.0f) {
+		const float ox = (1.0f - fabsf(y)) * (x >= 0.0f ? 1.0f : -1.0f);
+		const float oy = (1.0f - fabsf(x)) * (y >= 0.0f ? 1.0f : -1.0f);
+		x = ox;
+		y = oy;
+	}
+	float fu = (x * 0.5f + 0.5f) * (float)(1u << nu), fv = (y * 0.5f + 0.5f) * (float)(1u << nv);
+	fu = fu > 0.0f ? fu : 0.0f; // also drops NaN
+	fv = fv > 0.0f ? fv : 0.0f;
+	const u32 qu = fu < (float)((1u << nu) - 1u) ? (u32)fu : (1u << nu) - 1u;
+	const u32 qv = fv < (float)((1u << nv) - 1u) ? (u32)fv : (1u << nv) - 1u;
+	// nu >= nv >= nu - 1: u takes the even bits, so its extra bit is the top bit nu + nv - 1
+	return d_spread16(qu) | (d_spread16(qv) << 1);
+}
+
+// KEY64: (cell << 30) | 30-bit Z code of the direction in the cube, in a 64-bit key; otherwise
+// (cell << mbits) | mbits-bit octahedral code, in a 32-bit key (two radix passes fewer, half the key bytes)
+template <bool KEY64>
 __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const float *__restrict__ t_value_list,
 							     const float *__restrict__ ray_direction_list,
 							     const u32 *__restrict__ d_map, const u32 *__restrict__ prefix,
 							     u32 nchunks, u32 traced, u32 n, u32 C,
 							     const u32 *__restrict__ span, const float *__restrict__ cmPt,
-							     u64 *__restrict__ keys, u32 *__restrict__ vals)
+							     u32 mbits, void *__restrict__ keys, u32 *__restrict__ vals)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (i >= n)
@@ -532,22 +680,26 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 		rd[1] = (cmPt[1] + tVal * ray_direction_list[pixel * 3 + 1]) - cam.cc[1];
 		rd[2] = (cmPt[2] + tVal * ray_direction_list[pixel * 3 + 2]) - cam.cc[2];
 		D_NORMALIZE(rd);
-		code = d_dir_morton(rd);
+		code = KEY64 ? d_dir_morton(rd) : d_dir_oct(rd, (mbits + 1u) / 2u, mbits / 2u);
 	}
-	keys[i] = ((u64)cell << 30) | (u64)code;
+	if (KEY64)
+		((u64 *)keys)[i] = ((u64)cell << 30) | (u64)code;
+	else
+		((u32 *)keys)[i] = (cell << mbits) | code;
 	vals[i] = pixel;
 }
 
-__global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const u64 *__restrict__ keys, u32 n, u32 *__restrict__ rstart,
-							     u32 *__restrict__ rend)
+template <typename K>
+__global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const K *__restrict__ keys, u32 n, u32 shift,
+							     u32 *__restrict__ rstart, u32 *__restrict__ rend)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (i >= n)
 		return;
-	u32 c = (u32)(keys[i] >> 30);
-	if (i == 0 || (u32)(keys[i - 1] >> 30) != c)
+	u32 c = (u32)(keys[i] >> shift);
+	if (i == 0 || (u32)(keys[i - 1] >> shift) != c)
 		rstart[c] = i;
-	if (i == n - 1 || (u32)(keys[i + 1] >> 30) != c)
+	if (i == n - 1 || (u32)(keys[i + 1] >> shift) != c)
 		rend[c] = i + 1;
 }
 
@@ -997,7 +1149,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, maxg * 8)))
 		return rc;
-	u64 *k0 = (u64 *)ctx->skey[0].p, *k1 = (u64 *)ctx->skey[1].p;
+	void *k0 = ctx->skey[0].p, *k1 = ctx->skey[1].p;
 	u32 *v0 = (u32 *)ctx->sval[0].p, *v1 = (u32 *)ctx->sval[1].p;
 	u32 *rstart = (u32 *)ctx->sstart.p, *rend = rstart + ncellk;
 	u32 *gcnt = (u32 *)ctx->scnt.p, *icnt = gcnt + C, *gincl = (u32 *)ctx->sbase.p, *iincl = gincl + C;
@@ -1007,15 +1159,37 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	UGRT_HIP(hipMemsetAsync(wcnt, 0, 16, st));
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	// 1. rays: (cell, direction code) order, runs per cell, beams
-	hipLaunchKernelGGL(k_shadow_keys, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, ctx->cam,
-			   d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span, d_cam_position, k0,
-			   v0);
-	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_sort_pairs64(ctx, k0, k1, v0, v1, n, 30 + bits_of(ncellk))))
-		return rc;
+	// key = (light cell, direction code): 32 bits when the cell index leaves >= 12 bits for the code
+	const u32 cellbits = (u32)bits_of(ncellk);
+	bool key64 = cellbits > 20u;
+	if (const char *e = getenv("UGRT_SHADOW_KEY64"))
+		key64 = key64 || atoi(e) != 0;
+	u32 mbits = 32u - cellbits;
+	if (const char *e = getenv("UGRT_SHADOW_MBITS"))
+		mbits = (u32)atoi(e) < mbits ? (u32)atoi(e) : mbits;
+	mbits = mbits > 24u ? 24u : mbits;
+	if (key64) {
+		hipLaunchKernelGGL(k_shadow_keys<true>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
+				   d_cam_position, 30u, k0, v0);
+		UGRT_HIP(hipGetLastError());
+		if ((rc = ugrt_prim_sort_pairs64(ctx, (const u64 *)k0, (u64 *)k1, v0, v1, n, 30 + (int)cellbits)))
+			return rc;
+	} else {
+		hipLaunchKernelGGL(k_shadow_keys<false>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
+				   d_cam_position, mbits, k0, v0);
+		UGRT_HIP(hipGetLastError());
+		if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits))))
+			return rc;
+	}
 	UGRT_HIP(hipMemsetAsync(rstart, 0, (size_t)ncellk * 8, st));
-	hipLaunchKernelGGL(k_shadow_runs, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u64 *)k1, n, rstart, rend);
+	if (key64)
+		hipLaunchKernelGGL(k_shadow_runs<u64>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+				   (const u64 *)k1, n, 30u, rstart, rend);
+	else
+		hipLaunchKernelGGL(k_shadow_runs<u32>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+				   (const u32 *)k1, n, mbits, rstart, rend);
 	UGRT_HIP(hipGetLastError());
 	// rays per beam: the cull pass costs (triangles of the cell) x (beams of the cell); the exact pass
 	// re-culls the beam's candidates against each 64-ray sub-group, so its cost barely depends on the

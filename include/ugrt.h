@@ -28,6 +28,8 @@
 #ifndef UGRT_H
 #define UGRT_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -184,6 +186,14 @@ int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, const float 
 int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int num_faces,
 			    const float bbmin[3], const float bbmax[3]);
 int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out);
+/* cudppSort(plan, keys, values, bits, n) with CUDPP_SORT_RADIX on (uint key, uint value) pairs
+ * (cudpp/cudpp.h:426-471; call sites frustum_grid.h:298, decision_data.h:177): the stable radix sort
+ * the builds and the ray sort run on, exposed for callers that drive the stages themselves and for
+ * the tests.  Sorts on key bits [0, key_bits); inputs are left untouched; all pointers are device
+ * memory, outputs must not alias inputs.  use_library != 0 runs rocPRIM's radix sort instead of the
+ * built-in one (same result). */
+int ugrt_sort_pairs(ugrt_ctx *ctx, const unsigned *d_keys_in, unsigned *d_keys_out, const unsigned *d_values_in,
+		    unsigned *d_values_out, size_t n, int key_bits, int use_library);
 
 /* ---- device: tracing --------------------------------------------------- */
 /* FrustumTracer::trace(...), frustum_tracer.h:20-23 -> rckernel_alpha */

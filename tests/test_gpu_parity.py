@@ -385,6 +385,40 @@ def test_many_wide_triangles_tiny_grid(ugrt, O, torch):
     np.testing.assert_array_equal(u32(offset), g["offset"])
 
 
+@pytest.mark.parametrize("n,bits,kind", [
+    (1, 8, "rand"), (63, 1, "rand"), (255, 7, "rand"), (4096, 8, "rand"), (4097, 9, "rand"), (12345, 15, "rand"),
+    (100000, 16, "rand"), (1000003, 20, "rand"), (2073600, 32, "rand"), (3000000, 14, "runs"),
+    (2073600, 15, "few"), (500000, 24, "const"), (777777, 17, "desc"),
+])
+def test_radix_sort_is_the_stable_sort(ugrt, torch, n, bits, kind):
+    """The built-in radix sort against numpy's stable argsort on the sorted bits, and against rocPRIM's
+    through the same entry point: ragged tiles, every pass count, skewed digit histograms (all rays in a
+    few light cells), already sorted runs (the fill kernel's output), bits above key_bits ignored."""
+    rng = np.random.default_rng(n + bits)
+    if kind == "rand":
+        keys = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    elif kind == "runs":
+        keys = np.repeat(rng.integers(0, 2**bits, n // 50 + 1, dtype=np.uint64), 50)[:n].astype(np.uint32)
+    elif kind == "few":
+        keys = rng.choice(rng.integers(0, 2**bits, 97), n).astype(np.uint32)
+    elif kind == "const":
+        keys = np.full(n, 0xABCDEF, np.uint32)
+    else:
+        keys = np.arange(n, 0, -1, dtype=np.uint32)
+    vals = rng.permutation(n).astype(np.uint32)
+    ctx = ugrt.Context(64, 64)
+    dk, dv = ctx.upload(keys.view(np.int32)), ctx.upload(vals.view(np.int32))
+    mask = np.uint32((1 << bits) - 1) if bits < 32 else np.uint32(0xFFFFFFFF)
+    order = np.argsort(keys & mask, kind="stable")
+    for library in (False, True):
+        ok, ov = torch.empty_like(dk), torch.empty_like(dv)
+        ctx.sort_pairs(dk, ok, dv, ov, bits, library=library)
+        ctx.synchronize()
+        np.testing.assert_array_equal(u32(ok), keys[order])
+        np.testing.assert_array_equal(u32(ov), vals[order])
+        np.testing.assert_array_equal(u32(dk), keys)  # inputs untouched
+
+
 def test_known_answers_on_gpu(ugrt, torch):
     """centre tile, one triangle at z=-5 -> 64/64 hits, t=5, n=(0,0,1), dir=(0,0,-1), id 0."""
     verts = np.array([[-50, -50, -5], [50, -50, -5], [0, 50, -5]], np.float32)

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "ugrt_grid_build_spherical": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_float]),
     "ugrt_grid_build_uniform": (C.c_int, [_P, _P, _P, C.c_int, _F3, _F3]),
     "ugrt_grid_get_info": (C.c_int, [_P, C.c_int, C.POINTER(GridInfo)]),
+    "ugrt_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int]),
     "ugrt_trace_primary": (C.c_int, [_P] * 11),
     "ugrt_map_rays_to_light": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float]),
     "ugrt_sort_rays": (C.c_int, [_P, _P, _P, C.c_uint, C.POINTER(C.c_uint)]),

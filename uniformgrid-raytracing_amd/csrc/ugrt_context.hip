@@ -127,6 +127,9 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 		buf_free(G.offset);
 		}
 	buf_free(ctx->temp);
+	buf_free(ctx->rs_state);
+	buf_free(ctx->rs_tmp[0]);
+	buf_free(ctx->rs_tmp[1]);
 	buf_free(ctx->trirec);
 	buf_free(ctx->witems);
 	buf_free(ctx->wcount);

@@ -48,6 +48,7 @@ struct ugrt_ctx {
 	int p0 = 0, npix = 0; // first pixel and pixel count of this context's band
 	Grid grid[3];
 	DevBuf temp;                  // rocPRIM temporary storage
+	DevBuf rs_state, rs_tmp[2];   // own radix sort: histograms + tickets + look-back words, ping-pong buffers
 	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
 	// gather ONE record per reference instead of 3 indices + 3 vertices
 	DevBuf trirec;
@@ -89,6 +90,11 @@ int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
 // stable LSD radix sort of (key,value) pairs on key bits [0,end_bit)
 int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
 			 int end_bit);
+// the same on the library's onesweep (UGRT_SORT=rocprim, and the reference point of the sort tests)
+int ugrt_prim_sort_pairs_rocprim(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
+				 int end_bit);
+// ugrt_sort.hip
+int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit);
 int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,
 			   int end_bit);
 

@@ -42,6 +42,18 @@ int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n)
 int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
 			 int end_bit)
 {
+	static const bool use_library = [] {
+		const char *e = getenv("UGRT_SORT");
+		return e && strcmp(e, "rocprim") == 0;
+	}();
+	if (use_library || n > ((size_t)1 << 30))
+		return ugrt_prim_sort_pairs_rocprim(ctx, kin, kout, vin, vout, n, end_bit);
+	return ugrt_sort_pairs_u32(ctx, kin, kout, vin, vout, n, end_bit);
+}
+
+int ugrt_prim_sort_pairs_rocprim(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
+				 int end_bit)
+{
 	if (n == 0)
 		return UGRT_OK;
 	if (end_bit < 1)
@@ -78,4 +90,20 @@ int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *
 	UGRT_HIP(rocprim::radix_sort_pairs(ctx->temp.p, bytes, kin, kout, vin, vout, n, 0u, (unsigned)end_bit,
 					   ctx->stream));
 	return UGRT_OK;
+}
+
+extern "C" int ugrt_sort_pairs(ugrt_ctx *ctx, const unsigned *d_keys_in, unsigned *d_keys_out,
+			       const unsigned *d_values_in, unsigned *d_values_out, size_t n, int key_bits,
+			       int use_library)
+{
+	if (!ctx || (n && (!d_keys_in || !d_keys_out || !d_values_in || !d_values_out)))
+		return ugrt_fail(UGRT_EINVAL, "sort_pairs: null argument");
+	if (key_bits < 1 || key_bits > 32)
+		return ugrt_fail(UGRT_EINVAL, "sort_pairs: key_bits %d outside [1,32]", key_bits);
+	if (n && (d_keys_in == d_keys_out || d_values_in == d_values_out))
+		return ugrt_fail(UGRT_EINVAL, "sort_pairs: outputs alias inputs");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	if (use_library)
+		return ugrt_prim_sort_pairs_rocprim(ctx, d_keys_in, d_keys_out, d_values_in, d_values_out, n, key_bits);
+	return ugrt_prim_sort_pairs(ctx, d_keys_in, d_keys_out, d_values_in, d_values_out, n, key_bits);
 }

@@ -118,6 +118,11 @@ class Context:
                 self.wrap_u32(gi.d_triangle_key_list, gi.total_refs),
                 self.wrap_u32(gi.d_span, gi.num_cells), self.wrap_u32(gi.d_offset, gi.num_cells), gi)
 
+    def sort_pairs(self, keys_in, keys_out, values_in, values_out, key_bits, library=False):
+        """cudppSort on (uint key, uint value) pairs: stable, on key bits [0, key_bits)."""
+        check(lib.ugrt_sort_pairs(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(values_in), _ptr(values_out),
+                                  keys_in.numel(), key_bits, 1 if library else 0))
+
     # -- tracing -----------------------------------------------------------
     def trace_primary(self, value, span, offset, normal, t, ray_dir, shadowed, ids, verts, faces):
         check(lib.ugrt_trace_primary(self._h, _ptr(value), _ptr(span), _ptr(offset), _ptr(normal), _ptr(t),

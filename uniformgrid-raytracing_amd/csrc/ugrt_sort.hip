@@ -8,7 +8,7 @@
 // kernel (all digits in one read of the keys) and one kernel per pass, which scans the 256 digit totals
 // itself.
 //
-// Pass kernel, one workgroup of 512 threads per tile of 4096 pairs:
+// Pass kernel, one workgroup of 512 threads per tile of 8192 pairs:
 //   - tiles are taken in launch order from an atomic ticket, so a tile only ever waits for tiles that
 //     already run.  The tiles of these small sorts all start together, so a chained look-back (wait for
 //     the predecessor's inclusive prefix) would propagate through the tiles one round trip at a time.
@@ -24,7 +24,7 @@
 
 #define RS_THREADS 512
 #define RS_WAVES (RS_THREADS / 64)
-#define RS_ITEMS 8
+#define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
 #define RS_BINS 256
 #define RS_MAXPASS 4
@@ -42,19 +42,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
 		for (int p = 0; p < passes; p++)
 			s_h[p][threadIdx.x] = 0;
 	__syncthreads();
-	for (u32 i = blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += gridDim.x * RS_THREADS) {
-		const u32 k = keys[i];
-		const unsigned long long act = __ballot(true);
-		for (int p = 0; p < passes; p++) {
-			const u32 bits = end_bit - 8u * (u32)p < 8u ? end_bit - 8u * (u32)p : 8u;
-			const u32 d = (k >> (8 * p)) & ((1u << bits) - 1u);
-			// neighbouring keys mostly share their upper digits (cell ids in fill order): one add per wave then
-			const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
-			if (__ballot(d == d0) == act) {
-				if ((threadIdx.x & 63u) == (u32)__builtin_ctzll(act))
-					atomicAdd(&s_h[p][d0], (u32)__popcll(act));
-			} else {
-				atomicAdd(&s_h[p][d], 1u);
+	// few workgroups: every one ends with up to 256 * passes global adds on the same 256 * passes words
+	const u32 stride = gridDim.x * RS_THREADS;
+	for (u32 i0 = blockIdx.x * RS_THREADS + threadIdx.x; i0 < n; i0 += 4u * stride) {
+		u32 k4[4];
+#pragma unroll
+		for (u32 u = 0; u < 4; u++)
+			k4[u] = i0 + u * stride < n ? keys[i0 + u * stride] : 0u;
+#pragma unroll
+		for (u32 u = 0; u < 4; u++) {
+			const bool ok = i0 + u * stride < n;
+			const unsigned long long act = __ballot(ok);
+			if (!ok)
+				continue;
+			for (int p = 0; p < passes; p++) {
+				const u32 bits = end_bit - 8u * (u32)p < 8u ? end_bit - 8u * (u32)p : 8u;
+				const u32 d = (k4[u] >> (8 * p)) & ((1u << bits) - 1u);
+				// neighbouring keys mostly share their upper digits (cell ids in fill order): one add per wave then
+				const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+				if (__ballot(d == d0) == act) {
+					if ((threadIdx.x & 63u) == (u32)__builtin_ctzll(act))
+						atomicAdd(&s_h[p][d0], (u32)__popcll(act));
+				} else {
+					atomicAdd(&s_h[p][d], 1u);
+				}
 			}
 		}
 	}
@@ -108,13 +119,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const u32 *__restrict__ 
 	__syncthreads();
 	const u32 tile = s_tile;
 	const u32 base = tile * RS_TILE;
-	u32 k[RS_ITEMS], v[RS_ITEMS], r[RS_ITEMS];
+	u32 k[RS_ITEMS], r[RS_ITEMS];
 #pragma unroll
 	for (int i = 0; i < RS_ITEMS; i++) {
 		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
-		const bool ok = idx < n;
-		k[i] = ok ? kin[idx] : 0xFFFFFFFFu;
-		v[i] = ok ? vin[idx] : 0u;
+		k[i] = idx < n ? kin[idx] : 0xFFFFFFFFu;
 	}
 	// wave-synchronous ranking, items in memory order
 	volatile u32 *cnt = s_cnt[wave];
@@ -206,7 +215,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const u32 *__restrict__ 
 	s_base[t] = gdigit + excl - lstart;
 	} // digit
 	__syncthreads();
-	// tile in digit order in LDS
+	// tile in digit order in LDS (the values are fetched only now: they would occupy registers all the way)
+	u32 v[RS_ITEMS];
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++) {
+		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
+		v[i] = idx < n ? vin[idx] : 0u;
+	}
 #pragma unroll
 	for (int i = 0; i < RS_ITEMS; i++) {
 		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
@@ -256,7 +271,7 @@ int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin
 	u32 *hist = (u32 *)ctx->rs_state.p, *ticket = hist + (size_t)passes * RS_BINS, *look = ticket + RS_BINS;
 	UGRT_HIP(hipMemsetAsync(hist, 0, words * 4, st));
 	u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
-	hblocks = hblocks > 1024u ? 1024u : hblocks;
+	hblocks = hblocks > 256u ? 256u : hblocks;
 	hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, passes, (u32)end_bit, hist);
 	UGRT_HIP(hipGetLastError());
 	const u32 *ki = kin, *vi = vin;

@@ -205,25 +205,68 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const 
 // key = ((gx*ny + gy)*nz + gz).  Writes are fully coalesced and the work per
 // thread no longer depends on how many cells a triangle covers (border cells
 // collect thousands: SURVEY.md Q9).
-__global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
-							 int F, u32 R, int ny, int nz, u32 *__restrict__ keys,
-							 u32 *__restrict__ vals)
+// The search for f is split: k_fill_parts finds, for every workgroup of k_fill, the triangle of its first
+// reference (one 20-step search per 256 references); the workgroup then holds its short run of the scan
+// in LDS and its threads search that (a 20-step search of the global scan per REFERENCE diverges to 64
+// cache lines per wave in its last steps and was bound by the address path, not by bytes).
+#define FILL_LDS 1024
+__global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restrict__ scan, int F, u32 R, u32 nparts,
+							       u32 *__restrict__ parts)
 {
-	u32 r = blockIdx.x * BUILD_THREADS + threadIdx.x;
-	if (r >= R)
+	const u32 b = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (b > nparts)
 		return;
-	int lo = 0, hi = F - 1; // smallest f with scan[f] > r
+	u32 target = b * BUILD_THREADS; // first reference of workgroup b; parts[nparts] closes the last one
+	if (target >= R)
+		target = R - 1;
+	int lo = 0, hi = F - 1; // smallest f with scan[f] > target
 	while (lo < hi) {
 		int mid = (lo + hi) >> 1;
-		if (scan[mid] > r)
+		if (scan[mid] > target)
 			hi = mid;
 		else
 			lo = mid + 1;
 	}
-	int f = lo;
-	u32 base = f ? scan[f - 1] : 0;
-	u32 local = r - base;
-	Rng g = rng[f];
+	parts[b] = (u32)lo;
+}
+
+__global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
+							 const u32 *__restrict__ parts, u32 R, int ny, int nz,
+							 u32 *__restrict__ keys, u32 *__restrict__ vals)
+{
+	__shared__ u32 s_scan[FILL_LDS];
+	const u32 r = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	const int f_first = (int)parts[blockIdx.x], f_last = (int)parts[blockIdx.x + 1];
+	const int nrun = f_last - f_first + 1;
+	const bool in_lds = nrun <= FILL_LDS;
+	if (in_lds)
+		for (int i = threadIdx.x; i < nrun; i += BUILD_THREADS)
+			s_scan[i] = scan[f_first + i];
+	__syncthreads();
+	if (r >= R)
+		return;
+	int lo = f_first, hi = f_last; // smallest f with scan[f] > r
+	if (in_lds) {
+		while (lo < hi) {
+			int mid = (lo + hi) >> 1;
+			if (s_scan[mid - f_first] > r)
+				hi = mid;
+			else
+				lo = mid + 1;
+		}
+	} else {
+		while (lo < hi) {
+			int mid = (lo + hi) >> 1;
+			if (scan[mid] > r)
+				hi = mid;
+			else
+				lo = mid + 1;
+		}
+	}
+	const int f = lo;
+	const u32 base = (in_lds && f > f_first) ? s_scan[f - 1 - f_first] : (f ? scan[f - 1] : 0);
+	const u32 local = r - base;
+	const Rng g = rng[f];
 	u32 x0 = g.x & 0xFFFFu, y0 = g.y & 0xFFFFu, y1 = g.y >> 16, z0 = g.z & 0xFFFFu, z1 = g.z >> 16;
 	u32 sy = y1 - y0 + 1, sz = z1 - z0 + 1;
 	u32 k = local % sz;
@@ -269,17 +312,30 @@ __device__ __forceinline__ bool d_cell_active(const WideBox &wb, u32 c)
 __global__ __launch_bounds__(BUILD_THREADS) void k_span(const u32 *__restrict__ cstart, u32 *__restrict__ span_io,
 							 u32 C, u32 *__restrict__ used, WideBox wb)
 {
-	u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x;
-	u32 sp = 0;
-	if (c < C) {
-		sp = span_io[c] - cstart[c]; // span_io holds the run end on entry
+	// grid-stride on a few hundred workgroups: each ends with ONE add on `used` (a workgroup per 256 cells
+	// meant 4096 same-address atomics for the 2^20-cell uniform grid, 0.04 ms)
+	u32 mine = 0;
+	for (u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x; c < C; c += gridDim.x * BUILD_THREADS) {
+		u32 sp = span_io[c] - cstart[c]; // span_io holds the run end on entry
 		if (wb.W && d_cell_active(wb, c))
 			sp += wb.W;
 		span_io[c] = sp;
+		mine += sp != 0u ? 1u : 0u;
 	}
-	int cnt = __syncthreads_count(sp != 0);
-	if (threadIdx.x == 0 && cnt)
-		atomicAdd(used, (u32)cnt);
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		mine += (u32)__shfl_xor((int)mine, m);
+	__shared__ u32 s_cnt[BUILD_THREADS / 64];
+	if ((threadIdx.x & 63) == 0)
+		s_cnt[threadIdx.x >> 6] = mine;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u32 tot = 0;
+		for (int w = 0; w < BUILD_THREADS / 64; w++)
+			tot += s_cnt[w];
+		if (tot)
+			atomicAdd(used, tot);
+	}
 }
 
 // ascending order of the (few) wide triangle ids: rank = number of smaller ids
@@ -421,6 +477,8 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	if ((rc = ugrt_buf_reserve(ctx, G.key[0], rb0)) || (rc = ugrt_buf_reserve(ctx, G.val[0], rb0)) ||
 	    (rc = ugrt_buf_reserve(ctx, G.key[1], rb1)) || (rc = ugrt_buf_reserve(ctx, G.val[1], rb1)))
 		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, G.parts, ((size_t)Rn / BUILD_THREADS + 2) * 4))) // first triangle per fill workgroup
+		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 8 + 16))) // span[C], run starts[C], cells_used
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.offset, (size_t)C * 4)))
@@ -429,8 +487,11 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
 	if (Rn) {
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
-		hipLaunchKernelGGL(k_fill, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)G.scan.p, (const Rng *)G.rng.p, F, Rn, ny, nz, k0, v0);
+		const u32 nparts = (Rn + BUILD_THREADS - 1) / BUILD_THREADS;
+		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p);
+		hipLaunchKernelGGL(k_fill, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)G.scan.p,
+				   (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0);
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
@@ -463,7 +524,8 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 					   st, (const u32 *)k1, Rn, cstart, (u32 *)G.span.p);
 			UGRT_HIP(hipGetLastError());
 		}
-		hipLaunchKernelGGL(k_span, dim3((C + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+		const u32 span_blocks = (C + BUILD_THREADS - 1) / BUILD_THREADS;
+		hipLaunchKernelGGL(k_span, dim3(span_blocks < 512u ? span_blocks : 512u), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)cstart, (u32 *)G.span.p, C, used, wb);
 		UGRT_HIP(hipGetLastError());
 	}

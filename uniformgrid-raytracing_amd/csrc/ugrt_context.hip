@@ -119,6 +119,7 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 		buf_free(G.sizes);
 		buf_free(G.scan);
 		buf_free(G.wide);
+		buf_free(G.parts);
 		buf_free(G.key[0]);
 		buf_free(G.key[1]);
 		buf_free(G.val[0]);

@@ -25,6 +25,7 @@ struct DevBuf {
 
 struct Grid {
 	DevBuf rng, sizes, scan;          // per triangle
+	DevBuf parts;                     // fill: triangle of the first reference of every workgroup
 	DevBuf wide;                      // ids of the triangles that cover every cell: [F] as found, [F] ascending
 	DevBuf key[2], val[2];            // per ref, ping-pong for the radix sort
 	DevBuf span, offset;              // per cell (span buffer also holds run starts + cells_used)

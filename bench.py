@@ -182,7 +182,8 @@ def main():
 
     s = load_scene(ugrt, args.workload, args.scale, rank)
     setup = ugrt.FrameSetup.from_scene(s)
-    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS
+    # the renderer is the only writer of the vertex array (ugrt_animate): triangle records survive between builds
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY
     ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
     r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
     gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world, host_staging=rehearse)
@@ -214,6 +215,7 @@ def main():
                         uniform_dims=udims)
     cr = ugrt.Renderer(cctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
     cr.d_verts.copy_(r.d_verts)  # same geometry as the timed renderer (matters with --animate)
+    cctx.geometry_changed()
     cr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
     cctx.synchronize()
     st = cctx.stats()

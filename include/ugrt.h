@@ -53,7 +53,13 @@ enum {
 	UGRT_FLAG_SHADOW_ALL_CHUNKS = 1u,
 	/* tracers also count their work (DDA: candidates tested, cells visited, active rays) for
 	 * ugrt_stats_get; a counting context is for measurement set-up, never for timing */
-	UGRT_FLAG_COUNT_WORK = 2u
+	UGRT_FLAG_COUNT_WORK = 2u,
+	/* the caller promises that the vertex and face arrays passed to the grid builds only change
+	 * through ugrt_animate, or that it calls ugrt_geometry_changed after changing them itself
+	 * (the reference's other writer is the per-frame upload of scene.h:70 frames).  The builds then
+	 * keep the per-triangle records of the previous build instead of rewriting them three times a
+	 * frame.  Without the flag every build assumes new geometry, as the reference does. */
+	UGRT_FLAG_STATIC_GEOMETRY = 4u
 };
 
 /* which grid of the context */
@@ -186,6 +192,8 @@ int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, const float 
 int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int num_faces,
 			    const float bbmin[3], const float bbmax[3]);
 int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out);
+/* with UGRT_FLAG_STATIC_GEOMETRY: the vertex or face array was rewritten by the caller */
+int ugrt_geometry_changed(ugrt_ctx *ctx);
 /* cudppSort(plan, keys, values, bits, n) with CUDPP_SORT_RADIX on (uint key, uint value) pairs
  * (cudpp/cudpp.h:426-471; call sites frustum_grid.h:298, decision_data.h:177): the stable radix sort
  * the builds and the ray sort run on, exposed for callers that drive the stages themselves and for

@@ -44,6 +44,7 @@ lib = C.CDLL(LIB_PATH)
 UGRT_OK, UGRT_EINVAL, UGRT_ENODEV, UGRT_EHIP, UGRT_EIO, UGRT_ENOMEM = range(6)
 FLAG_SHADOW_ALL_CHUNKS = 1
 FLAG_COUNT_WORK = 2
+FLAG_STATIC_GEOMETRY = 4
 GRID_PERSPECTIVE, GRID_SPHERICAL, GRID_UNIFORM = 0, 1, 2
 STAGES = [
     "build_count", "build_scan", "build_fill", "build_sort", "build_bounds", "trace_primary", "map_rays",
@@ -115,6 +116,7 @@ PROTOTYPES = {
     "ugrt_grid_build_spherical": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_float]),
     "ugrt_grid_build_uniform": (C.c_int, [_P, _P, _P, C.c_int, _F3, _F3]),
     "ugrt_grid_get_info": (C.c_int, [_P, C.c_int, C.POINTER(GridInfo)]),
+    "ugrt_geometry_changed": (C.c_int, [_P]),
     "ugrt_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int]),
     "ugrt_trace_primary": (C.c_int, [_P] * 11),
     "ugrt_map_rays_to_light": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float]),

@@ -571,7 +571,13 @@ static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const f
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.wide, (size_t)F * 8))) // wide triangle ids as found, then ascending
 		return rc;
-	// the geometry may have changed since the last build (animation, a new frame file): refresh the records
+	// the geometry may have changed since the last build (animation, a new frame file): refresh the records,
+	// unless the caller vouches for it (UGRT_FLAG_STATIC_GEOMETRY) and these are the arrays last seen
+	if ((ctx->cfg.flags & UGRT_FLAG_STATIC_GEOMETRY) && ctx->rec_valid && ctx->rec_verts == d_vertlist &&
+	    ctx->rec_tris == d_facelist && ctx->rec_faces == F) {
+		UGRT_HIP(hipMemsetAsync(ugrt_wide_counter(ctx), 0, 4, ctx->stream));
+		return UGRT_OK;
+	}
 	ctx->rec_valid = false;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->trirec, (size_t)F * 48)))
 		return rc;
@@ -580,6 +586,7 @@ static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const f
 	UGRT_HIP(hipGetLastError());
 	ctx->rec_verts = d_vertlist;
 	ctx->rec_tris = d_facelist;
+	ctx->rec_faces = F;
 	ctx->rec_valid = true;
 	return UGRT_OK;
 }
@@ -659,4 +666,12 @@ extern "C" int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, con
 	UGRT_HIP(hipGetLastError());
 	return build_common(ctx, G, F, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], g.dims[1], g.dims[2], 0,
 			    g.dims[1] - 1);
+}
+
+extern "C" int ugrt_geometry_changed(ugrt_ctx *ctx)
+{
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "geometry_changed: null context");
+	ctx->rec_valid = false;
+	return UGRT_OK;
 }

@@ -55,6 +55,7 @@ struct ugrt_ctx {
 	DevBuf trirec;
 	const float *rec_verts = nullptr;
 	const int *rec_tris = nullptr;
+	int rec_faces = 0;
 	bool rec_valid = false;
 	DevBuf witems, wcount, wscan; // tracer work lists
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells

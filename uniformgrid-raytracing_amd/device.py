@@ -118,6 +118,10 @@ class Context:
                 self.wrap_u32(gi.d_triangle_key_list, gi.total_refs),
                 self.wrap_u32(gi.d_span, gi.num_cells), self.wrap_u32(gi.d_offset, gi.num_cells), gi)
 
+    def geometry_changed(self):
+        """With FLAG_STATIC_GEOMETRY: the vertex or face array was rewritten outside ugrt_animate."""
+        check(lib.ugrt_geometry_changed(self._h))
+
     def sort_pairs(self, keys_in, keys_out, values_in, values_out, key_bits, library=False):
         """cudppSort on (uint key, uint value) pairs: stable, on key bits [0, key_bits)."""
         check(lib.ugrt_sort_pairs(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(values_in), _ptr(values_out),

@@ -88,10 +88,16 @@ struct PrimaryOut {
 
 // trace_kernel.cu:56-82 isWithin + :230-267 epilogue for one pixel.
 // `ref` = index into value_list of the nearest accepted triangle, ~0u = none.
+template <bool REC>
+__device__ __forceinline__ void d_load_triangle(const float4 *__restrict__ rec, const float *__restrict__ verts,
+						const int *__restrict__ tris, u32 face, float ox, float oy, float oz,
+						float *t9);
+
+template <bool REC>
 __device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const PrimaryOut &o, int pixelID,
 					       const float *dir, float oldt, u32 ref,
 					       const u32 *__restrict__ value_list, const float *__restrict__ verts,
-					       const int *__restrict__ tris)
+					       const int *__restrict__ tris, const float4 *__restrict__ rec)
 {
 	bool ok = false;
 	if (ref != 0xFFFFFFFFu) {
@@ -107,7 +113,8 @@ __device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const Primar
 	if (ok) {
 		u32 face = value_list[ref];
 		float tri[9];
-		d_stage_triangle(verts, tris, face, 0.0f, 0.0f, 0.0f, tri);
+		// the record holds the same two edge subtractions (one 48-B gather instead of three indices + nine floats)
+		d_load_triangle<REC>(rec, verts, tris, face, 0.0f, 0.0f, 0.0f, tri);
 		float *e1 = &tri[3], *e2 = &tri[6], nrm[3];
 		D_NORMALIZE(e1);
 		D_NORMALIZE(e2);
@@ -180,6 +187,7 @@ __device__ __forceinline__ DirBox d_dir_box(const float *d, bool valid)
 
 __device__ __forceinline__ void d_interval_dot(const float *n, const DirBox &bx, float *fmin, float *fmax)
 {
+#pragma clang fp contract(fast)
 	float mn = 0.0f, mx = 0.0f;
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
@@ -197,6 +205,7 @@ __device__ __forceinline__ bool d_cull(const float *tv, const float *e1, const f
 #ifdef UGRT_DEBUG_CULL_ALL
 	return (tv[0] + tv[1] + tv[2] + e1[0] + e1[1] + e1[2] + e2[0] + e2[1] + e2[2]) != 12345.678f;
 #endif
+#pragma clang fp contract(fast)
 	float nA[3], nB[3], nD[3], nC[3];
 	D_CROSS(nA, e2, tv);
 	D_CROSS(nB, tv, e1);
@@ -275,8 +284,11 @@ struct CBox {
 	float c[3], r[3];
 };
 
+// (The cull is outside the numeric contract: it only has to be conservative, and its margins are 2^6
+// times the rounding error, so its dot products may contract to FMAs; the exact tests never do.)
 __device__ __forceinline__ CullTri d_cull_prep(const float *tv, const float *e1, const float *e2)
 {
+#pragma clang fp contract(fast)
 	CullTri t;
 	D_CROSS(t.nA, e2, tv);
 	D_CROSS(t.nB, tv, e1);
@@ -296,6 +308,7 @@ __device__ __forceinline__ CullTri d_cull_prep(const float *tv, const float *e1,
 
 __device__ __forceinline__ bool d_cull_cr(const CullTri &t, const CBox &bx)
 {
+#pragma clang fp contract(fast)
 	const float Dm = t.nD[0] * bx.c[0] + t.nD[1] * bx.c[1] + t.nD[2] * bx.c[2];
 	const float Dr = fabsf(t.nD[0]) * bx.r[0] + fabsf(t.nD[1]) * bx.r[1] + fabsf(t.nD[2]) * bx.r[2];
 	if (!(Dm + Dr < 1e15f && Dm - Dr > -1e15f))
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(64, 5) void k_trace_primary(CamBlock cam, const flo
 			qn[0] = qn[1] = qn[2] = qn[3] = 0;
 		}
 		if (!w.multi) {
-			d_finish_pixel(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris);
+			d_finish_pixel<REC>(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris, rec);
 		} else if (ref != 0xFFFFFFFFu) {
 			atomicMin(reinterpret_cast<unsigned long long *>(&best[pixelID - p0]),
 				  ((unsigned long long)__float_as_uint(oldt) << 32) | (unsigned long long)ref);
@@ -450,11 +463,13 @@ __global__ __launch_bounds__(64, 5) void k_trace_primary(CamBlock cam, const flo
 }
 
 // pixels of split cells: take the merged (t, ref), finish, re-arm the slot
+template <bool REC>
 __global__ __launch_bounds__(256) void k_resolve_primary(CamBlock cam, const float *__restrict__ tex,
 							  const u32 *__restrict__ span,
 							  const u32 *__restrict__ value_list,
 							  const float *__restrict__ verts, const int *__restrict__ tris,
-							  PrimaryOut out, u64 *__restrict__ best, int p0, int npix, u32 SEG)
+							  const float4 *__restrict__ rec, PrimaryOut out,
+							  u64 *__restrict__ best, int p0, int npix, u32 SEG)
 {
 	int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= npix)
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(256) void k_resolve_primary(CamBlock cam, const flo
 	float oldt = (b == ~0ull) ? 99999999.9f : __uint_as_float((u32)(b >> 32));
 	if (b == ~0ull)
 		ref = 0xFFFFFFFFu;
-	d_finish_pixel(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris);
+	d_finish_pixel<REC>(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris, rec);
 }
 
 static int launch_blocks_for(u32 upper)
@@ -561,9 +576,14 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
-	hipLaunchKernelGGL(k_resolve_primary, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
-			   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist, out,
-			   (u64 *)ctx->best.p, ctx->p0, ctx->npix, SEG);
+	if (use_rec)
+		hipLaunchKernelGGL(k_resolve_primary<true>, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
+				   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist,
+				   (const float4 *)ctx->trirec.p, out, (u64 *)ctx->best.p, ctx->p0, ctx->npix, SEG);
+	else
+		hipLaunchKernelGGL(k_resolve_primary<false>, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
+				   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist,
+				   (const float4 *)nullptr, out, (u64 *)ctx->best.p, ctx->p0, ctx->npix, SEG);
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	ctx->stats[0] = cap; // upper bound of primary work items
@@ -843,6 +863,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 						    const GBox *__restrict__ boxes, u32 *__restrict__ pair_count, u32 pair_cap,
 						    u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri, u32 sbits)
 {
+#pragma clang fp contract(fast) // cull arithmetic only (conservative by margin); no exact test in this kernel
 	// candidate pairs are staged in LDS and flushed PAIR_BUF at a time: one atomic on the shared
 	// output cursor per ~450 pairs instead of one per beam iteration
 	__shared__ u32 buf_beam[PAIR_BUF], buf_tri[PAIR_BUF];

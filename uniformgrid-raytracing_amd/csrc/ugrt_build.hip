@@ -232,10 +232,15 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restr
 
 __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
 							 const u32 *__restrict__ parts, u32 R, int ny, int nz,
-							 u32 *__restrict__ keys, u32 *__restrict__ vals)
+							 u32 *__restrict__ keys, u32 *__restrict__ vals,
+							 u32 *__restrict__ zero, u32 nzero)
 {
 	__shared__ u32 s_scan[FILL_LDS];
 	const u32 r = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	// the per-cell words the boundary kernels start from (run ends, run starts, cells_used) are cleared here
+	// instead of by a fill of their own
+	for (u32 i = r; i < nzero; i += gridDim.x * BUILD_THREADS)
+		zero[i] = 0;
 	const int f_first = (int)parts[blockIdx.x], f_last = (int)parts[blockIdx.x + 1];
 	const int nrun = f_last - f_first + 1;
 	const bool in_lds = nrun <= FILL_LDS;
@@ -431,6 +436,10 @@ __global__ __launch_bounds__(64) void k_merge_wide(const u32 *__restrict__ nvals
 	}
 }
 
+// number of wide triangles of the running build: kept right behind the scan of the sizes, so that
+// total_refs (scan[F-1]) and this count come back in one 8-byte copy
+static inline u32 *wide_counter(Grid &G, int F) { return (u32 *)G.scan.p + F; }
+
 static int bits_for(u32 C)
 {
 	int b = 1;
@@ -447,8 +456,6 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	int rc;
 	G.valid = false;
 	G.C = C;
-	if ((rc = ugrt_buf_reserve(ctx, G.scan, (size_t)F * 4)))
-		return rc;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SCAN);
 	rc = ugrt_prim_inclusive_scan(ctx, (const u32 *)G.sizes.p, (u32 *)G.scan.p, (size_t)F);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_SCAN);
@@ -456,8 +463,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		return rc;
 	// total_triangles, frustum_grid.h:254 (the one unavoidable read-back: it sizes the lists), here
 	// as narrow references + number of wide triangles
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned, (u32 *)G.scan.p + (F - 1), 4, hipMemcpyDeviceToHost, st));
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 1, ugrt_wide_counter(ctx), 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned, (u32 *)G.scan.p + (F - 1), 8, hipMemcpyDeviceToHost, st));
 	UGRT_HIP(hipStreamSynchronize(st));
 	const u32 Rn = ctx->h_pinned[0], W = ctx->h_pinned[1];
 	WideBox wb;
@@ -491,7 +497,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p);
 		hipLaunchKernelGGL(k_fill, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)G.scan.p,
-				   (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0);
+				   (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0, (u32 *)G.span.p, 2u * C + 1u);
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
@@ -508,16 +514,15 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 			UGRT_HIP(hipGetLastError());
 		} else {
 			// many wide triangles (a tiny grid): radix sort of the ids, the values are not used
-			if ((rc = ugrt_buf_reserve(ctx, G.scan, (size_t)F * 4)))
-				return rc;
-			if ((rc = ugrt_prim_sort_pairs(ctx, wl, wsorted, wl, (u32 *)G.scan.p, W, bits_for((u32)F))))
+			if ((rc = ugrt_prim_sort_pairs(ctx, wl, wsorted, wl, (u32 *)G.sizes.p, W, bits_for((u32)F))))
 				return rc;
 		}
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 	}
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
 	u32 *cstart = (u32 *)G.span.p + C, *used = cstart + C;
-	UGRT_HIP(hipMemsetAsync(G.span.p, 0, (size_t)C * 8 + 4, st)); // one fill for all three
+	if (!Rn)
+		UGRT_HIP(hipMemsetAsync(G.span.p, 0, (size_t)C * 8 + 4, st)); // (otherwise cleared by k_fill)
 	if (R) {
 		if (Rn) {
 			hipLaunchKernelGGL(k_bounds, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
@@ -569,20 +574,22 @@ static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const f
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.sizes, (size_t)F * 4)))
 		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, G.scan, (size_t)(F + 1) * 4))) // + the wide-triangle counter
+		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, G.wide, (size_t)F * 8))) // wide triangle ids as found, then ascending
 		return rc;
 	// the geometry may have changed since the last build (animation, a new frame file): refresh the records,
 	// unless the caller vouches for it (UGRT_FLAG_STATIC_GEOMETRY) and these are the arrays last seen
 	if ((ctx->cfg.flags & UGRT_FLAG_STATIC_GEOMETRY) && ctx->rec_valid && ctx->rec_verts == d_vertlist &&
 	    ctx->rec_tris == d_facelist && ctx->rec_faces == F) {
-		UGRT_HIP(hipMemsetAsync(ugrt_wide_counter(ctx), 0, 4, ctx->stream));
+		UGRT_HIP(hipMemsetAsync(wide_counter(G, F), 0, 4, ctx->stream));
 		return UGRT_OK;
 	}
 	ctx->rec_valid = false;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->trirec, (size_t)F * 48)))
 		return rc;
 	hipLaunchKernelGGL(k_tri_records, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
-			   ctx->stream, d_facelist, d_vertlist, F, (float4 *)ctx->trirec.p, ugrt_wide_counter(ctx));
+			   ctx->stream, d_facelist, d_vertlist, F, (float4 *)ctx->trirec.p, wide_counter(G, F));
 	UGRT_HIP(hipGetLastError());
 	ctx->rec_verts = d_vertlist;
 	ctx->rec_tris = d_facelist;
@@ -601,7 +608,7 @@ extern "C" int ugrt_grid_build_perspective(ugrt_ctx *ctx, const int *d_facelist,
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_persp, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, ctx->cfg.row_begin, ctx->cfg.row_end,
-			   (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p, ugrt_wide_counter(ctx));
+			   (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F));
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
 	G.dims[0] = ctx->nbx;
@@ -623,7 +630,7 @@ extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, c
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_sph, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, lx, ly, xM, yM, (Rng *)G.rng.p,
-			   (u32 *)G.sizes.p, (u32 *)G.wide.p, ugrt_wide_counter(ctx));
+			   (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F));
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
 	G.dims[0] = lx;
@@ -661,7 +668,7 @@ extern "C" int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, con
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_uniform, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, g, d_facelist, d_vertlist, F, (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p,
-			   ugrt_wide_counter(ctx));
+			   wide_counter(G, F));
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
 	return build_common(ctx, G, F, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], g.dims[1], g.dims[2], 0,

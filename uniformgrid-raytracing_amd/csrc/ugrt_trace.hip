@@ -680,9 +680,12 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 							     const u32 *__restrict__ d_map, const u32 *__restrict__ prefix,
 							     u32 nchunks, u32 traced, u32 n, u32 C,
 							     const u32 *__restrict__ span, const float *__restrict__ cmPt,
-							     u32 mbits, void *__restrict__ keys, u32 *__restrict__ vals)
+							     u32 mbits, void *__restrict__ keys, u32 *__restrict__ vals,
+							     u32 *__restrict__ zero, u32 nzero)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
+	for (u32 z = i; z < nzero; z += gridDim.x * WL_THREADS)
+		zero[z] = 0; // run starts/ends per light cell, written after the sort
 	if (i >= n)
 		return;
 	const u32 M = traced < nchunks ? prefix[traced] : n;
@@ -787,8 +790,11 @@ __global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__
 						     const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
 						     const u32 *__restrict__ ray_pixels, const float *__restrict__ t_value_list,
 						     const float *__restrict__ ray_direction_list,
-						     const float *__restrict__ cmPt, GBox *__restrict__ boxes, u32 beam)
+						     const float *__restrict__ cmPt, GBox *__restrict__ boxes, u32 beam,
+						     u32 *__restrict__ zero, u32 nzero)
 {
+	for (u32 z = blockIdx.x * 64u + threadIdx.x; z < nzero; z += gridDim.x * 64u)
+		zero[z] = 0; // candidate run starts/ends per beam, written after the pair sort
 	const u32 total = gincl[C - 1];
 	const int lane = threadIdx.x;
 	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
@@ -1177,7 +1183,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = pstart + maxg;
 	GBox *boxes = (GBox *)ctx->sdesc.p;
 	unsigned long long *wcnt = (unsigned long long *)(ctx->d_small + 16); // [0] cull tests, [1] staged candidates
-	UGRT_HIP(hipMemsetAsync(wcnt, 0, 16, st));
+	UGRT_HIP(hipMemsetAsync(wcnt, 0, 16 + 4, st)); // + the candidate-pair cursor
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	// 1. rays: (cell, direction code) order, runs per cell, beams
 	// key = (light cell, direction code): 32 bits when the cell index leaves >= 12 bits for the code
@@ -1192,19 +1198,18 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if (key64) {
 		hipLaunchKernelGGL(k_shadow_keys<true>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, 30u, k0, v0);
+				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk);
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs64(ctx, (const u64 *)k0, (u64 *)k1, v0, v1, n, 30 + (int)cellbits)))
 			return rc;
 	} else {
 		hipLaunchKernelGGL(k_shadow_keys<false>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, mbits, k0, v0);
+				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk);
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits))))
 			return rc;
 	}
-	UGRT_HIP(hipMemsetAsync(rstart, 0, (size_t)ncellk * 8, st));
 	if (key64)
 		hipLaunchKernelGGL(k_shadow_runs<u64>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 				   (const u64 *)k1, n, 30u, rstart, rend);
@@ -1235,7 +1240,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64), 0, st, ctx->cam,
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
-			   d_ray_dir, d_cam_position, boxes, beam);
+			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg));
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	u32 sbits = 4u;
@@ -1243,7 +1248,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		sbits = (u32)atoi(e);
 	sbits = sbits > 8u ? 8u : sbits;
 	// 2. cull pass -> (beam, triangle) candidate pairs; grows the pair buffer and repeats if it was too small
-	u32 *pcount = ctx->d_small + 1;
+	u32 *pcount = ctx->d_small + 20; // right behind the work counters: cleared with them
 	u32 P = 0;
 	for (int attempt = 0; attempt < 3; attempt++) {
 		size_t cap = ctx->tkey[0].cap / 4;
@@ -1263,7 +1268,8 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			cap = ctx->tval[1].cap / 4;
 		if (cap > 0xFFFFFFF0u)
 			cap = 0xFFFFFFF0u;
-		UGRT_HIP(hipMemsetAsync(pcount, 0, 4, st));
+		if (attempt)
+			UGRT_HIP(hipMemsetAsync(pcount, 0, 4, st));
 		ugrt_prof_begin(ctx, UGRT_ST_SHADOW_CULL);
 		if (use_rec)
 			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
@@ -1297,7 +1303,6 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
 				       (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits)))
 		return rc;
-	UGRT_HIP(hipMemsetAsync(pstart, 0, maxg * 8, st));
 	hipLaunchKernelGGL(k_pair_runs, dim3((P + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 			   (const u32 *)ctx->tkey[1].p, P, sbits, pstart, pend);
 	UGRT_HIP(hipGetLastError());

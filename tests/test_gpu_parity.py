@@ -474,6 +474,62 @@ def test_known_answers_on_gpu(ugrt, torch):
     assert (centre > 0).all() and np.allclose(centre * -d[28:36, 28:36, 2], 5.0, atol=1e-5)
 
 
+def _frame_equals_oracle(ugrt, O, s, setup, W, H, lg, ud, reflect=True):
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    for _ in range(2):
+        r.display(setup, shadows=True, reflect=reflect)
+        ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=reflect, uniform_dims=ud)
+    pr = want["primary"]
+    np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"])
+    assert_bits_equal(r.t.cpu().numpy(), pr["t"], "t")
+    assert_bits_equal(r.normal.cpu().numpy(), pr["normal"], "normal")
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"])
+    if reflect:
+        np.testing.assert_array_equal(r.active.cpu().numpy(), want["active"])
+        np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want["hit_id"])
+        assert_bits_equal(r.hit_t.cpu().numpy(), want["hit_t"], "dda t")
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+    return want
+
+
+def test_all_rays_miss(ugrt, O, torch):
+    """The camera is far from the scene and looks past it (the reference takes |t|, so looking AWAY is not enough:
+    geometry behind the eye still hits, Q1): no hit, no shadow ray group with work, no secondary ray; every
+    stage still runs (empty work lists, zero candidate pairs) and the frame is the oracle's."""
+    s = scene(ugrt, "cornell")
+    cam = dict(s["cameras"]["B"])
+    cam["eye"], cam["look"] = (278, 5000, 278), (279, 5000, 278)  # far above the 556-unit box, looking level
+    setup = ugrt.FrameSetup(cam, s["light_camera"], s["shading_light"])
+    want = _frame_equals_oracle(ugrt, O, s, setup, 64, 64, (16, 16), (8, 8, 4))
+    assert (want["mat_ids"] < 0).all() and want["image"].max() == 0
+
+
+def test_degenerate_triangles(ugrt, O, torch):
+    """Zero-area triangles (repeated vertices, collinear vertices), a triangle of one point, coincident
+    duplicates and a sliver 1e-7 wide among the scene's own: the culls must stay conservative through the
+    NaN / zero determinants they produce, and the frame must be the oracle's."""
+    s0 = scene(ugrt, "cornell")
+    verts = np.asarray(s0["verts"], np.float32).reshape(-1, 3)
+    lo, hi = verts.min(0), verts.max(0)
+    c = (lo + hi) / 2
+    extra = np.array([
+        c, c, c,                                             # a point
+        c, c + (hi - lo) * 0.1, c,                           # repeated vertex
+        lo, c, hi,                                           # collinear
+        lo + (hi - lo) * [0.2, 0.2, 0.5], lo + (hi - lo) * [0.8, 0.2, 0.5], lo + (hi - lo) * [0.5, 0.2 + 1e-7, 0.5],  # sliver
+        verts[0], verts[1], verts[2],                        # duplicate of the first triangle's corners
+    ], np.float32)
+    v2 = np.concatenate([verts, extra])
+    f_extra = (len(verts) + np.arange(len(extra), dtype=np.int32)).reshape(-1, 3)
+    s = dict(s0)
+    s.update(verts=v2, faces=np.concatenate([np.asarray(s0["faces"], np.int32), f_extra]),
+             matidx=np.concatenate([np.asarray(s0["matidx"], np.int32), np.zeros(len(f_extra), np.int32)]))
+    setup = setup_for(ugrt, s0, "B")
+    want = _frame_equals_oracle(ugrt, O, s, setup, 128, 128, (32, 32), (8, 8, 4))
+    assert (want["mat_ids"] >= 0).sum() > 1000
+
+
 def test_error_paths(ugrt, torch):
     with pytest.raises(ugrt.UgrtError) as e:
         ugrt.Context(250, 256)

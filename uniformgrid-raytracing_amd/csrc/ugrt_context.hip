@@ -155,6 +155,7 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->tval[1]);
 	buf_free(ctx->tbcnt);
 	buf_free(ctx->sitem);
+	buf_free(ctx->citem);
 	if (ctx->h_pinned)
 		(void)hipHostFree(ctx->h_pinned);
 	if (ctx->d_small)

@@ -609,7 +609,7 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 //   3. the pair list is sorted by beam (rocPRIM), and
 //   4. EXACT pass, lane = ray: each beam runs the reference's per-ray test on its own short list.
 // The cull is conservative with margins far above fp32 rounding, so the flags do not change.
-#define GCHUNK 256u // beams a cull work item streams past its 64 triangles
+#define GCHUNK 32u  // beams a cull work item streams past its 64 triangles
 
 struct GBox { // one beam (re-grouped rays of one light cell)
 	float cx, cy, cz; // centre of the direction box
@@ -757,6 +757,25 @@ __device__ __forceinline__ u32 d_find_cell(const u32 *__restrict__ incl, u32 C, 
 	return lo;
 }
 
+// The same for a wave-uniform x with all 64 lanes probing at once: 64-ary instead of binary, three dependent
+// loads for 16 k cells instead of fourteen.
+__device__ __forceinline__ u32 d_find_cell_wave(const u32 *__restrict__ incl, u32 C, u32 x, int lane)
+{
+	u32 lo = 0, n = C; // the answer lies in [lo, lo + n) and incl[lo + n - 1] > x
+	while (n > 1u) {
+		const u32 stride = (n + 63u) / 64u;
+		u32 idx = lo + ((u32)lane + 1u) * stride - 1u;
+		idx = idx < lo + n - 1u ? idx : lo + n - 1u;
+		const unsigned long long above = __ballot(incl[idx] > x);
+		const u32 f = (u32)__builtin_ctzll(above);
+		const u32 nlo = lo + f * stride;
+		const u32 left = lo + n - nlo;
+		lo = nlo;
+		n = stride < left ? stride : left;
+	}
+	return lo;
+}
+
 // the rays of a beam, as the reference rebuilds them (light_kernel.cu:166-184)
 struct ShadowRay {
 	float rd[3];
@@ -859,6 +878,17 @@ __device__ __forceinline__ void d_flush_pairs(const u32 *buf_beam, const u32 *bu
 	__syncthreads();
 }
 
+// light cell of every cull item (the first CULL_TABLE of them; a frame has some 10^4): one load at the head of
+// an item instead of a search whose probes all miss the L1 when 8192 waves start together
+#define CULL_TABLE (1u << 20)
+__global__ __launch_bounds__(WL_THREADS) void k_cull_items(const u32 *__restrict__ iincl, u32 C,
+							    u32 *__restrict__ item_cell)
+{
+	const u32 it = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (it < CULL_TABLE && it < iincl[C - 1])
+		item_cell[it] = d_find_cell(iincl, C, it);
+}
+
 // CULL pass.  item -> (cell, batch of 64 triangles, chunk of GCHUNK beams).  Same test as d_cull
 // with the box as centre +- half width: f(d) = n.d ranges over n.c -+ sum_k |n_k| r_k.
 template <bool REC>
@@ -867,7 +897,8 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 						    const u32 *__restrict__ value_list, const float4 *__restrict__ rec,
 						    const float *__restrict__ verts, const int *__restrict__ tris,
 						    const GBox *__restrict__ boxes, u32 *__restrict__ pair_count, u32 pair_cap,
-						    u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri, u32 sbits)
+						    u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri, u32 sbits,
+						    const u32 *__restrict__ item_cell)
 {
 #pragma clang fp contract(fast) // cull arithmetic only (conservative by margin); no exact test in this kernel
 	// candidate pairs are staged in LDS and flushed PAIR_BUF at a time: one atomic on the shared
@@ -878,7 +909,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 	const int lane = threadIdx.x;
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
 	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
-		const u32 c = d_find_cell(iincl, C, it);
+		const u32 c = it < CULL_TABLE ? item_cell[it] : d_find_cell_wave(iincl, C, it, lane);
 		const u32 sp = span[c];
 		const u32 nb = (sp + 63u) / 64u;
 		const u32 ngrp = gincl[c] - (c ? gincl[c - 1] : 0u);
@@ -1242,6 +1273,11 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
 			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg));
 	UGRT_HIP(hipGetLastError());
+	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * 4)))
+		return rc;
+	hipLaunchKernelGGL(k_cull_items, dim3(CULL_TABLE / WL_THREADS), dim3(WL_THREADS), 0, st, (const u32 *)iincl, C,
+			   (u32 *)ctx->citem.p);
+	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	u32 sbits = 4u;
 	if (const char *e = getenv("UGRT_SHADOW_SIZEBITS"))
@@ -1274,11 +1310,13 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		if (use_rec)
 			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
-					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits);
+					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits,
+					   (const u32 *)ctx->citem.p);
 		else
 			hipLaunchKernelGGL(k_shadow_cull<false>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
-					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits);
+					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits,
+					   (const u32 *)ctx->citem.p);
 		ugrt_prof_end(ctx, UGRT_ST_SHADOW_CULL);
 		UGRT_HIP(hipGetLastError());
 		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, pcount, 4, hipMemcpyDeviceToHost, st));

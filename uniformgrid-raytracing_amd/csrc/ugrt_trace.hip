@@ -1067,7 +1067,8 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      const float4 *__restrict__ rec, const float *__restrict__ t_value_list,
 						      const float *__restrict__ ray_direction_list,
 						      int *__restrict__ is_shadowed, const u32 *__restrict__ ray_pixels,
-						      const float *__restrict__ cmPt, u32 XSEG)
+						      const float *__restrict__ cmPt, u32 XSEG, u32 *__restrict__ sub_done,
+						      u32 nsubmax)
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
 	const int lane = threadIdx.x;
@@ -1080,20 +1081,31 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		const GBox bx = boxes[g];
 		const u32 p0 = pstart[g] + sgm * XSEG;
 		const u32 p1 = (sgm != XSEG_LAST && (p0 + XSEG) < pend[g]) ? (p0 + XSEG) : pend[g];
+		// Three quarters of the items find every ray of their sub-group flagged by an earlier segment (the
+		// point of the segment-major order).  The sub-group says so in one word, and the flags are looked
+		// at before the rays are rebuilt: an item that has nothing to do ends after one or two loads.
+		u32 *my_done = sub_done + (size_t)g * nsubmax + sub;
+		if (__hip_atomic_load(my_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+			continue;
 		const bool have_ray = 64u * sub + (u32)lane < bx.ray_count;
 		ShadowRay r;
 		r.rd[0] = r.rd[1] = r.rd[2] = 0.0f;
 		r.distance_b = 0.0f;
 		r.pixel = 0;
 		bool done = true; // rayDoneMap == 2
+		int pixel = 0;
 		if (have_ray) {
-			r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm,
-					 (int)ray_pixels[bx.ray_start + 64u * sub + lane]);
+			pixel = (int)ray_pixels[bx.ray_start + 64u * sub + lane];
 			// a ray already flagged by another segment of its beam needs no more tests
-			done = is_shadowed[r.pixel] == 1;
+			done = is_shadowed[pixel] == 1;
 		}
-		if (__ballot(!done) == 0ull)
+		if (__ballot(!done) == 0ull) {
+			if (lane == 0)
+				__hip_atomic_store(my_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			continue;
+		}
+		if (have_ray)
+			r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm, pixel);
 		// the candidates were found for the whole beam; this wave's 64 (still undecided) rays are a
 		// narrower packet, so each staged candidate is culled once more against their own box
 		const DirBox box = d_dir_box(r.rd, !done);
@@ -1144,6 +1156,8 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		}
 		if (hit)
 			is_shadowed[r.pixel] = 1;
+		if (__ballot(!done) == 0ull && lane == 0)
+			__hip_atomic_store(my_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -1203,7 +1217,8 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sdesc, maxg * sizeof(GBox))))
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->tbcnt, maxg * 8))) // candidate run starts, then ends, per beam
+	// candidate run starts, then ends, per beam; then one "all rays flagged" word per 64-ray sub-group
+	if ((rc = ugrt_buf_reserve(ctx, ctx->tbcnt, maxg * 8 + maxg * 128 * 4)))
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, maxg * 8)))
 		return rc;
@@ -1271,7 +1286,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64), 0, st, ctx->cam,
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
-			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg));
+			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg + maxg * (beam / 64u)));
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * 4)))
 		return rc;
@@ -1376,12 +1391,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
-				   (const u32 *)v1, d_cam_position, XSEG);
+				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u);
 	else
 		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
-				   (const u32 *)v1, d_cam_position, XSEG);
+				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

@@ -63,6 +63,7 @@ struct ugrt_ctx {
 	DevBuf rstart, cchunks, cbase; // ray runs per light cell (sort_rays)
 	DevBuf skey[2], sval[2], sdesc, sstart, scnt, sbase; // shadow tracer: re-grouped rays, beams, counts
 	DevBuf tkey[2], tval[2], tbcnt;                      // shadow tracer: candidate pairs, runs per beam
+	DevBuf sray;                                         // shadow tracer: rebuilt rays {direction, distance}, beam order
 	DevBuf citem;                                        // shadow tracer: light cell of every cull item
 	DevBuf sitem;                                        // shadow tracer: exact-pass item list (segment, beam|sub) x2
 	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs

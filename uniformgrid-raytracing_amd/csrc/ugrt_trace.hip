@@ -810,7 +810,7 @@ __global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__
 						     const u32 *__restrict__ ray_pixels, const float *__restrict__ t_value_list,
 						     const float *__restrict__ ray_direction_list,
 						     const float *__restrict__ cmPt, GBox *__restrict__ boxes, u32 beam,
-						     u32 *__restrict__ zero, u32 nzero)
+						     u32 *__restrict__ zero, u32 nzero, float4 *__restrict__ sray)
 {
 	for (u32 z = blockIdx.x * 64u + threadIdx.x; z < nzero; z += gridDim.x * 64u)
 		zero[z] = 0; // candidate run starts/ends per beam, written after the pair sort
@@ -835,6 +835,9 @@ __global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__
 				rd[0] = r.rd[0];
 				rd[1] = r.rd[1];
 				rd[2] = r.rd[2];
+				// the rebuilt ray, in beam order: the exact pass reads 64 of them as one 1-KB run instead of
+				// gathering t and direction per pixel for every (segment, sub-group) item again
+				sray[start + b + lane] = make_float4(r.rd[0], r.rd[1], r.rd[2], r.distance_b);
 			}
 			const DirBox bx = d_dir_box(rd, have);
 #pragma unroll
@@ -1068,13 +1071,12 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      const float *__restrict__ ray_direction_list,
 						      int *__restrict__ is_shadowed, const u32 *__restrict__ ray_pixels,
 						      const float *__restrict__ cmPt, u32 XSEG, u32 *__restrict__ sub_done,
-						      u32 nsubmax)
+						      u32 nsubmax, const float4 *__restrict__ sray)
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
 	const int lane = threadIdx.x;
 	const u32 total = xincl[G - 1];
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
-	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
 	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
 		const u32 sgm = item_seg[it], gs = item_sub[it];
 		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list
@@ -1104,8 +1106,14 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 				__hip_atomic_store(my_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			continue;
 		}
-		if (have_ray)
-			r = d_shadow_ray(cam, t_value_list, ray_direction_list, cm, pixel);
+		if (have_ray) {
+			const float4 q = sray[bx.ray_start + 64u * sub + lane]; // = d_shadow_ray(pixel), stored by k_shadow_boxes
+			r.rd[0] = q.x;
+			r.rd[1] = q.y;
+			r.rd[2] = q.z;
+			r.distance_b = q.w;
+			r.pixel = pixel;
+		}
 		// the candidates were found for the whole beam; this wave's 64 (still undecided) rays are a
 		// narrower packet, so each staged candidate is culled once more against their own box
 		const DirBox box = d_dir_box(r.rd, !done);
@@ -1222,6 +1230,8 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, maxg * 8)))
 		return rc;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->sray, (size_t)n * 16))) // rebuilt shadow rays in beam order
+		return rc;
 	void *k0 = ctx->skey[0].p, *k1 = ctx->skey[1].p;
 	u32 *v0 = (u32 *)ctx->sval[0].p, *v1 = (u32 *)ctx->sval[1].p;
 	u32 *rstart = (u32 *)ctx->sstart.p, *rend = rstart + ncellk;
@@ -1286,7 +1296,8 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64), 0, st, ctx->cam,
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
-			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg + maxg * (beam / 64u)));
+			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg + maxg * (beam / 64u)),
+			   (float4 *)ctx->sray.p);
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * 4)))
 		return rc;
@@ -1391,12 +1402,14 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
-				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u);
+				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
+				   (const float4 *)ctx->sray.p);
 	else
 		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
-				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u);
+				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
+				   (const float4 *)ctx->sray.p);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

@@ -100,7 +100,7 @@ __device__ __forceinline__ u32 d_block_excl_scan(u32 v, u32 *s_part)
 	return base + incl - v;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
+__global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
 							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
 							 u32 dmask, const u32 *__restrict__ hist, u32 *look, u32 *look2,
 							 u32 *ticket)

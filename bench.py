@@ -62,7 +62,8 @@ def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
     gi = ctx.grid_info(ugrt.GRID_PERSPECTIVE)
     out["trace_primary"] = 8 * C_band + 52 * gi.total_refs + 36 * ctx.npix
     # shadow: 24 N + sum over traced chunks (8 + 52 span(cell(chunk)))
-    _, _, lspan, _, lgi = ctx.grid_arrays(ugrt.GRID_SPHERICAL)
+    gctx = r.aux if r.aux is not None else ctx  # the light and uniform grids live in the second context when overlapped
+    _, _, lspan, _, lgi = gctx.grid_arrays(ugrt.GRID_SPHERICAL)
     n, nch = ctx.npix, r.num_chunks
     heads = r.prefix[:nch].long()
     cells = r.d_map[n:2 * n][heads].long()
@@ -80,7 +81,7 @@ def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
     out["trace_dda"] = 48 * active + 8 * cells_visited + 52 * tests
     out["_R_perspective"], out["_R_spherical"] = gi.total_refs, lgi.total_refs
     try:
-        out["_R_uniform"] = ctx.grid_info(ugrt.GRID_UNIFORM).total_refs
+        out["_R_uniform"] = gctx.grid_info(ugrt.GRID_UNIFORM).total_refs
     except Exception:
         out["_R_uniform"] = 0
     out["_shadow_span_sum"], out["_chunks"] = int(sp.sum().item()), nch
@@ -136,6 +137,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--stages-json", default="", help="also write the per-stage table to this file")
     ap.add_argument("--no-reflect", action="store_true", help="primary + shadow only (BASELINE configs[1])")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one stream: every stage after the other (default: light/uniform grid builds and the bounce "
+                         "on a second stream beside the camera and shadow passes)")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
@@ -185,7 +189,8 @@ def main():
     # the renderer is the only writer of the vertex array (ugrt_animate): triangle records survive between builds
     flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY
     ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
-    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
+                      overlap=not args.no_overlap)
     gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world, host_staging=rehearse)
 
     reflect = not args.no_reflect
@@ -230,29 +235,42 @@ def main():
     # dominant kernel's live launch time); every other stage is timed in a separate, untimed pass below,
     # because ~40 event pairs per frame would themselves cost about 7 % of the frame.
     tracers = ("trace_primary", "shadow_cull", "trace_shadow", "trace_dda")
-    ctx.prof_enable(True, stages=tracers)
-    ctx.prof_reset()
+    profiled = [ctx] + ([r.aux] if r.aux is not None else [])  # events are recorded on the stream a kernel runs on
+
+    def merged_prof():
+        out = {}
+        for c in profiled:
+            for k, v in c.prof_get().items():
+                a = out.get(k, (0.0, 0))
+                out[k] = (a[0] + v[0], a[1] + v[1])
+        return out
+
+    for c in profiled:
+        c.prof_enable(True, stages=tracers)
+        c.prof_reset()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ctx.synchronize()
+    r.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.prof_get()
-    # untimed pass: the full stage table
-    ctx.prof_enable(True)
-    ctx.prof_reset()
+    prof = merged_prof()
+    # untimed pass: the full stage table (with two streams the stages overlap: their sum exceeds the frame)
+    for c in profiled:
+        c.prof_enable(True)
+        c.prof_reset()
     nfull = min(args.steps, 10)
     for _ in range(nfull):
         step()
-    ctx.synchronize()
-    prof_full = ctx.prof_get()
-    ctx.prof_enable(False)
+    r.synchronize()
+    prof_full = merged_prof()
+    for c in profiled:
+        c.prof_enable(False)
 
     tot = torch.tensor([elapsed, float(rays_rank)], dtype=torch.float64, device="cpu" if rehearse else ctx.device)
     if dist is not None:
@@ -332,6 +350,7 @@ def main():
             "frames_per_s": round(args.steps / elapsed, 2),
             "rays_per_frame": int(rays_total),
             "tile": 8, "light_grid": list(lg), "uniform_grid": list(udims),
+            "streams": 1 if args.no_overlap else 2,
             "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",
         },
         "roofline": roofline,

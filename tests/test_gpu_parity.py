@@ -385,19 +385,21 @@ def test_many_wide_triangles_tiny_grid(ugrt, O, torch):
     np.testing.assert_array_equal(u32(offset), g["offset"])
 
 
-def test_static_geometry_flag(ugrt, O, torch):
-    """FLAG_STATIC_GEOMETRY keeps the triangle records between builds; ugrt_animate and geometry_changed()
+@pytest.mark.parametrize("overlap", [False, True])
+def test_static_geometry_flag(ugrt, O, torch, overlap):
+    """(overlap: the two-stream frame, whose second context must hear of every geometry change too.)
+    FLAG_STATIC_GEOMETRY keeps the triangle records between builds; ugrt_animate and geometry_changed()
     invalidate them.  Frames must equal the oracle's before and after both kinds of change."""
     s = scene(ugrt, "cornell")
     W, H, lg = 128, 128, (32, 32)
     ctx = ugrt.Context(W, H, light_grid=lg, flags=ugrt.FLAG_STATIC_GEOMETRY)
-    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=overlap)
     setup = setup_for(ugrt, s, "B")
 
     def check(verts):
         for _ in range(2):  # the second frame runs on kept records
             r.display(setup, shadows=True)
-            ctx.synchronize()
+            r.synchronize()
         want = O.frame(s, setup, W, H, light_grid=lg, verts=verts)
         np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"])
         assert_bits_equal(r.t.cpu().numpy(), want["primary"]["t"], "t")
@@ -409,6 +411,8 @@ def test_static_geometry_flag(ugrt, O, torch):
     v2 = (np.asarray(s["verts"], np.float32) * np.float32(0.75)).astype(np.float32)
     r.d_verts.copy_(torch.from_numpy(v2.reshape(-1)).to(r.d_verts.device))
     ctx.geometry_changed()
+    if r.aux is not None:
+        r.aux.geometry_changed()
     check(v2)
     # ugrt_animate rewrites a sub-range
     r.init_orig_list(8, 16)
@@ -417,6 +421,7 @@ def test_static_geometry_flag(ugrt, O, torch):
     v3 = r.d_verts.cpu().numpy().reshape(-1, 3).copy()
     assert np.abs(v3 - v2).max() > 1e-3
     check(v3)
+    r.close()
 
 
 @pytest.mark.parametrize("n,bits,kind", [

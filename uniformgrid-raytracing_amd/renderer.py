@@ -46,10 +46,13 @@ class Renderer:
     def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False):
         """overlap=True: the light grid and the uniform grid (which do not depend on the camera pass) are built
         by a second context on a second HIP stream while the main stream builds the perspective grid and
-        traces the primary rays; streams are joined with events before the grids are consumed.  Same results."""
+        traces the primary rays; streams are joined with events before the grids are consumed.  Same results.
+        A grid build blocks its caller once (the read-back of total_refs), so the second context is driven by
+        a helper thread: both streams then really run side by side."""
         t = ctx.torch
         self.ctx = ctx
         self.aux = None
+        self._worker = None
         if overlap:
             from .device import Context
 
@@ -59,6 +62,24 @@ class Renderer:
                 self.aux = Context(ctx.width, ctx.height, device=ctx.device_index, light_grid=ctx.light_grid,
                                    rows=ctx.rows, flags=int(ctx.cfg.flags),
                                    uniform_dims=tuple(ctx.cfg.uniform_dims[k] for k in range(3)))
+            import queue
+            import threading
+
+            self._jobs, self._done = queue.Queue(), queue.Queue()
+
+            def loop():
+                while True:
+                    job = self._jobs.get()
+                    if job is None:
+                        return
+                    try:
+                        job()
+                        self._done.put(None)
+                    except BaseException as e:  # handed to the frame loop
+                        self._done.put(e)
+
+            self._worker = threading.Thread(target=loop, name="ugrt-aux", daemon=True)
+            self._worker.start()
         self.F = int(len(faces))
         self.num_materials = int(len(mat_list) // 6 if np.ndim(mat_list) == 1 else len(mat_list))
         self.d_verts = ctx.upload(np.asarray(verts, np.float32).reshape(-1))
@@ -95,6 +116,15 @@ class Renderer:
     # Model::rotate_bunny, scene.h:122
     def rotate_bunny(self, rot):
         self.ctx.animate(self.d_verts, self.orig, self.orig_size, self.orig_offset, rot)
+        if self.aux is not None:
+            self.aux.geometry_changed()  # the second context did not see the call
+
+    def close(self):
+        """Stops the helper thread of an overlapped renderer."""
+        if self._worker is not None:
+            self._jobs.put(None)
+            self._worker.join()
+            self._worker = None
 
     def _ensure_reflect_buffers(self):
         if self.rays is None:
@@ -154,45 +184,69 @@ class Renderer:
             ctx.shade_add_shadows(self.image, self.is_shadowed)
 
     def _display_overlapped(self, setup, frame_cnt, shadows, reflect):
-        """display() with the camera-independent grid builds on the second stream."""
+        """display() on two streams.  Side stream (second context, driven by the helper thread): light grid,
+        uniform grid, then - once the primary hits exist - secondary rays and the 3D-DDA.  Main stream: screen
+        grid, primary rays, ray mapping and sort, shadow rays (after the light grid), shading (after the DDA).
+        The shadow pass and the bounce only depend on the primary hits, not on each other."""
+        import threading
+
         ctx, aux, t = self.ctx, self.aux, self.ctx.torch
         main, side = self.main_stream, self.aux_stream
         lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
+        if reflect:
+            self._ensure_reflect_buffers()
+        ev_primary, ev_light_grid = t.cuda.Event(), t.cuda.Event()
+        primary_recorded, light_grid_recorded = threading.Event(), threading.Event()
         # side stream: starts once the geometry of this frame is final on the main stream
         side.wait_stream(main)
-        if shadows:
-            aux.upload_camera(lcam.camcoords)
-            aux.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
-        if reflect:
-            aux.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
-        # main stream: the camera pass
-        ctx.set_light_position(setup.shading_light)
-        cam = make_camera(setup.camera, setup.fovy, self.aspect)
-        self.cam_pos.copy_(t.from_numpy(cam.worldori[:3].copy()), non_blocking=False)
-        ctx.upload_camera(cam.camcoords)
-        ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
-        value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
-        ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed, self.intersect_id,
-                          self.d_verts, self.d_faces)
+
+        def side_job():
+            try:
+                if shadows:
+                    aux.upload_camera(lcam.camcoords)
+                    aux.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
+                    ev_light_grid.record(side)
+            finally:
+                light_grid_recorded.set()
+            if reflect:
+                aux.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
+                primary_recorded.wait()
+                side.wait_event(ev_primary)
+                aux.reflect_rays(self.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
+                                 self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays,
+                                 self.active)
+                uvalue, uspan, uoffset, _ = aux.grid_ptrs(GRID_UNIFORM)
+                aux.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active,
+                              self.hit_t, self.hit_id)
+
+        self._jobs.put(side_job)
+        try:
+            # main stream: the camera pass
+            ctx.set_light_position(setup.shading_light)
+            cam = make_camera(setup.camera, setup.fovy, self.aspect)
+            self.cam_pos.copy_(t.from_numpy(cam.worldori[:3].copy()), non_blocking=False)
+            ctx.upload_camera(cam.camcoords)
+            ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
+            value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
+            ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed,
+                              self.intersect_id, self.d_verts, self.d_faces)
+            ev_primary.record(main)
+        finally:
+            primary_recorded.set()
         ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
         if shadows:
             ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
             self.num_chunks = ctx.sort_rays(self.d_map, self.prefix)
-            main.wait_stream(side)  # light grid ready
+            light_grid_recorded.wait()
+            main.wait_event(ev_light_grid)
             lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
             ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
                              self.d_map, self.prefix, self.cam_pos, self.num_chunks)
+        err = self._done.get()  # the side stream's work is enqueued
+        if err is not None:
+            raise err
+        main.wait_stream(side)
         if reflect:
-            self._ensure_reflect_buffers()
-            ctx.reflect_rays(self.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
-                             self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays,
-                             self.active)
-            # the traversal runs where the uniform grid's geometry lives
-            side.wait_stream(main)
-            uvalue, uspan, uoffset, _ = aux.grid_ptrs(GRID_UNIFORM)
-            aux.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active, self.hit_t,
-                          self.hit_id)
-            main.wait_stream(side)
             ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
                               self.d_matidx, self.d_matlist, self.d_reflect, self.num_materials, self.d_verts,
                               self.d_faces, self.rays, self.active, self.hit_t, self.hit_id)

@@ -595,6 +595,55 @@ def test_full_size_bench_workload(ugrt, O, torch):
     assert (pr["id"][a:b] >= 0).sum() > 1000 and want["is_shadowed"][a:b].sum() > 100
 
 
+def test_4k_frame_bands_and_oracle(ugrt, O, torch):
+    """BASELINE configs[3]: the 1 M-triangle scene at 3840x2160 (129 600 screen cells: 17-bit sort keys, three
+    radix passes).  The full frame on one context, the same frame as two half-image bands (the multi-GPU
+    split) and the two-stream renderer must agree byte for byte; the oracle checks two tile rows."""
+    s = ugrt.scenes.crash(scale=1.0)
+    W, H, lg, ud = 3840, 2160, (128, 128), (128, 128, 64)
+    setup = setup_for(ugrt, s, "ref")
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS
+    ctx, r = make(ugrt, s, W, H, lg, flags=flags, udims=ud)
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    N, nby = W * H, H // 8
+    value, key, span, offset, gi = ctx.grid_arrays(ugrt.GRID_PERSPECTIVE)
+    k = u32(key).astype(np.int64)
+    assert gi.num_cells == 129600 and (np.diff(k) >= 0).all() and k.max() >= 1 << 16
+    np.testing.assert_array_equal(np.bincount(k, minlength=gi.num_cells), u32(span).astype(np.int64))
+    full = {n: getattr(r, n).cpu().numpy().copy() for n in ("t", "is_shadowed", "hit_id", "hit_t", "intersect_id", "image")}
+    del value, key, span, offset
+    # two bands = what two ranks compute
+    for rows in ((0, nby // 2), (nby // 2, nby)):
+        bctx, br = make(ugrt, s, W, H, lg, rows=rows, flags=flags, udims=ud)
+        br.display(setup, shadows=True, reflect=True)
+        bctx.synchronize()
+        a, b = bctx.p0, bctx.p0 + bctx.npix
+        for n in ("t", "is_shadowed", "hit_id", "hit_t", "intersect_id"):
+            np.testing.assert_array_equal(getattr(br, n).cpu().numpy()[a:b].view(np.uint32), full[n][a:b].view(np.uint32),
+                                          err_msg="band %s %s" % (rows, n))
+        np.testing.assert_array_equal(br.image.cpu().numpy()[3 * a:3 * b], full["image"][3 * a:3 * b])
+        del br, bctx
+    # two streams
+    octx = ugrt.Context(W, H, light_grid=lg, flags=flags, uniform_dims=ud)
+    orr = ugrt.Renderer(octx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True)
+    for _ in range(2):
+        orr.display(setup, shadows=True, reflect=True)
+    orr.synchronize()
+    torch.cuda.synchronize()
+    for n in full:
+        np.testing.assert_array_equal(getattr(orr, n).cpu().numpy().view(np.uint8), full[n].view(np.uint8), err_msg=n)
+    orr.close()
+    # the oracle on two tile rows
+    rows = (135, 137)
+    want = O.frame(s, setup, W, H, rows=rows, light_grid=lg, all_chunks=True, reflect=True, uniform_dims=ud)
+    a, b = want["p0"], want["p0"] + want["n"]
+    np.testing.assert_array_equal(full["t"][a:b].view(np.uint32), want["primary"]["t"][a:b].view(np.uint32))
+    np.testing.assert_array_equal(full["is_shadowed"][a:b], want["is_shadowed"][a:b])
+    np.testing.assert_array_equal(full["hit_id"][a:b], want["hit_id"][a:b])
+    np.testing.assert_array_equal(full["image"][3 * a:3 * b], want["image"][3 * a:3 * b])
+
+
 def test_gather_path_without_records(ugrt, O, torch):
     """When the caller's vertex/face arrays are not the ones the grids were last built from, the tracers fall
     back to gathering 3 indices + 3 vertices per reference (the reference's own staging); same results."""

@@ -207,6 +207,7 @@ def main():
 
     for _ in range(max(1, args.warmup)):
         step()
+    gather.finish()
     ctx.synchronize()
     torch.cuda.synchronize()
 
@@ -254,6 +255,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    gather.finish()  # the last frame's bands are in rank 0's image
     r.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
@@ -267,6 +269,7 @@ def main():
     nfull = min(args.steps, 10)
     for _ in range(nfull):
         step()
+    gather.finish()
     r.synchronize()
     prof_full = merged_prof()
     for c in profiled:

@@ -42,6 +42,8 @@ def _worker(rank, world, port, W, H, out_path):
         image = torch.from_numpy(fr["image"].copy())
         g = parallel.BandGather(dist, torch, torch.device("cpu"), W, nby, rank, world)
         g.gather(image)
+        g.gather(image)  # a second frame: the first one's bands are placed, the buffers are reused
+        g.finish()
         dist.barrier()
         if rank == 0:
             np.save(out_path, image.numpy())

@@ -43,17 +43,33 @@ class BandGather:
         return (e - b) * 8 * self.width * 3
 
     def gather(self, image):
-        """image: uint8 [3*W*H] on the device; rank 0's copy receives all bands."""
+        """image: uint8 [3*W*H] on the device.  Starts this frame's gather and returns: the collective runs
+        beside the next frame (it only reads the staging copy of the band made here), and the received bands
+        are placed into rank 0's image by the next call or by finish().  The renderer of rank 0 only ever
+        writes its own band, so the late placement cannot collide with the next frame."""
+        if self.world == 1:
+            return image
+        self._complete()
         b, _ = self.bands[self.rank]
         off = b * 8 * self.width * 3
         n = self.band_bytes(self.rank)
-        if self.world == 1:
-            return image
         self.send[:n].copy_(image[off:off + n])  # (device -> host when staging)
-        self.dist.gather(self.send, self.recv, dst=0)
+        self._work = self.dist.gather(self.send, self.recv, dst=0, async_op=True)
+        self._image = image
+        return image
+
+    def finish(self):
+        """Waits for the gather in flight; rank 0's image then holds every band of the last gathered frame."""
+        self._complete()
+
+    def _complete(self):
+        work, image = getattr(self, "_work", None), getattr(self, "_image", None)
+        if work is None:
+            return
+        work.wait()  # device backends: the current stream waits, the host does not
+        self._work = None
         if self.rank == 0:
             for r in range(1, self.world):
                 rb, _ = self.bands[r]
                 roff, rn = rb * 8 * self.width * 3, self.band_bytes(r)
                 image[roff:roff + rn].copy_(self.recv[r][:rn])
-        return image

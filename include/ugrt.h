@@ -173,6 +173,10 @@ int ugrt_rot_cos_sin(float rot, float *c, float *s);
 /* ---- device: context --------------------------------------------------- */
 int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cfg);
 int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
+/* launch-shape options of this context; none changes a result.  key "dda_rays_per_wave": 1..64 secondary
+ * rays per wave of ugrt_trace_dda (default 32: fastest when the traversal has the GPU to itself; 64 halves its
+ * waves, which a context that runs beside another stream's kernels is better off with); 0 = default. */
+int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value);
 int ugrt_ctx_synchronize(ugrt_ctx *ctx);
 void ugrt_ctx_destroy(ugrt_ctx *ctx);
 

@@ -173,6 +173,19 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	delete ctx;
 }
 
+extern "C" int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value)
+{
+	if (!ctx || !key)
+		return ugrt_fail(UGRT_EINVAL, "ctx_set_option: null argument");
+	if (strcmp(key, "dda_rays_per_wave") == 0) {
+		if (value < 0 || value > 64)
+			return ugrt_fail(UGRT_EINVAL, "ctx_set_option: dda_rays_per_wave %d outside [0,64]", value);
+		ctx->opt_dda_rpw = value;
+		return UGRT_OK;
+	}
+	return ugrt_fail(UGRT_EINVAL, "ctx_set_option: unknown key '%s'", key);
+}
+
 extern "C" int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream)
 {
 	if (!ctx)

@@ -1721,7 +1721,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	}
 	UGRT_HIP(hipGetLastError());
 	// rays per wave / list length from which the whole wave tests a cell (tunable for experiments)
-	u32 DDA_RPW = 32u, DDA_COOP = 8u;
+	u32 DDA_RPW = ctx->opt_dda_rpw > 0 ? (u32)ctx->opt_dda_rpw : 32u, DDA_COOP = 8u;
 	if (const char *e = getenv("UGRT_DDA_RPW"))
 		DDA_RPW = (u32)atoi(e);
 	if (const char *e = getenv("UGRT_DDA_COOP"))

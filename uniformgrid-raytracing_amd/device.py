@@ -118,6 +118,10 @@ class Context:
                 self.wrap_u32(gi.d_triangle_key_list, gi.total_refs),
                 self.wrap_u32(gi.d_span, gi.num_cells), self.wrap_u32(gi.d_offset, gi.num_cells), gi)
 
+    def set_option(self, key, value):
+        """Launch-shape options (no effect on results), e.g. "dda_rays_per_wave"."""
+        check(lib.ugrt_ctx_set_option(self._h, key.encode(), int(value)))
+
     def geometry_changed(self):
         """With FLAG_STATIC_GEOMETRY: the vertex or face array was rewritten outside ugrt_animate."""
         check(lib.ugrt_geometry_changed(self._h))

@@ -221,6 +221,10 @@ int ugrt_map_rays_to_light(ugrt_ctx *ctx, const float *d_t_value, const float *d
  * prefix_capacity entries must fit: n/64 + light cells + 1 always does. */
 int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity,
 		   unsigned *num_chunks);
+/* num_chunks may be NULL: the call then does not wait for the device; the count is passed on to
+ * ugrt_trace_shadow as UGRT_CHUNKS_ON_DEVICE and can be fetched later (this call waits for the stream): */
+int ugrt_sort_rays_chunks(ugrt_ctx *ctx, unsigned *num_chunks);
+#define UGRT_CHUNKS_ON_DEVICE 0xFFFFFFFFu
 /* check_for_shadows(int), per_frame_funcs.h:139 -> mod_light_rckernel; same
  * argument order as the kernel (light_kernel.cu:53) */
 int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, const float *d_vertlist,

@@ -45,6 +45,7 @@ UGRT_OK, UGRT_EINVAL, UGRT_ENODEV, UGRT_EHIP, UGRT_EIO, UGRT_ENOMEM = range(6)
 FLAG_SHADOW_ALL_CHUNKS = 1
 FLAG_COUNT_WORK = 2
 FLAG_STATIC_GEOMETRY = 4
+CHUNKS_ON_DEVICE = 0xFFFFFFFF
 GRID_PERSPECTIVE, GRID_SPHERICAL, GRID_UNIFORM = 0, 1, 2
 STAGES = [
     "build_count", "build_scan", "build_fill", "build_sort", "build_bounds", "trace_primary", "map_rays",
@@ -122,6 +123,7 @@ PROTOTYPES = {
     "ugrt_trace_primary": (C.c_int, [_P] * 11),
     "ugrt_map_rays_to_light": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float]),
     "ugrt_sort_rays": (C.c_int, [_P, _P, _P, C.c_uint, C.POINTER(C.c_uint)]),
+    "ugrt_sort_rays_chunks": (C.c_int, [_P, C.POINTER(C.c_uint)]),
     "ugrt_trace_shadow": (C.c_int, [_P] * 12 + [C.c_uint]),
     "ugrt_shade_simple": (C.c_int, [_P] * 9 + [C.c_int]),
     "ugrt_shade_spotlight": (C.c_int, [_P] * 9 + [C.c_int, _P]),

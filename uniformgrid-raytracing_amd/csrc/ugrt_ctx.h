@@ -69,6 +69,7 @@ struct ugrt_ctx {
 	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
 	u32 *d_small = nullptr;       // 16 u32 of device scratch (totals)
 	unsigned prof_mask = 0; // bit s = stage s is timed
+	unsigned chunk_capacity = 0; // prefix_capacity of the last ugrt_sort_rays
 	int opt_dda_rpw = 0;    // ugrt_ctx_set_option "dda_rays_per_wave" (0 = default)
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;

@@ -117,7 +117,7 @@ static int key_bits(u32 nkeys)
 extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity,
 			      unsigned *num_chunks)
 {
-	if (!ctx || !d_map || !d_prefix_map || !num_chunks)
+	if (!ctx || !d_map || !d_prefix_map)
 		return ugrt_fail(UGRT_EINVAL, "sort_rays: null argument");
 	UGRT_HIP(hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
@@ -162,11 +162,22 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 	// h_numCudaBlocks, decision_data.h:264
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 11, (u32 *)ctx->cbase.p + (ncell - 1), 4, hipMemcpyDeviceToHost, st));
 	ugrt_prof_end(ctx, UGRT_ST_SORT_RAYS);
-	UGRT_HIP(hipStreamSynchronize(st));
+	ctx->chunk_capacity = prefix_capacity;
+	if (!num_chunks)
+		return UGRT_OK; // deferred: the count stays on the device (UGRT_CHUNKS_ON_DEVICE) until ugrt_sort_rays_chunks
+	return ugrt_sort_rays_chunks(ctx, num_chunks);
+}
+
+extern "C" int ugrt_sort_rays_chunks(ugrt_ctx *ctx, unsigned *num_chunks)
+{
+	if (!ctx || !num_chunks)
+		return ugrt_fail(UGRT_EINVAL, "sort_rays_chunks: null argument");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
 	*num_chunks = ctx->h_pinned[11];
-	if (*num_chunks > prefix_capacity)
+	if (*num_chunks > ctx->chunk_capacity)
 		return ugrt_fail(UGRT_EINVAL, "sort_rays: %u chunks do not fit prefix_capacity %u", *num_chunks,
-				 prefix_capacity);
+				 ctx->chunk_capacity);
 	return UGRT_OK;
 }
 

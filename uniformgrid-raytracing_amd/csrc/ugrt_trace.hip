@@ -681,13 +681,19 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 							     u32 nchunks, u32 traced, u32 n, u32 C,
 							     const u32 *__restrict__ span, const float *__restrict__ cmPt,
 							     u32 mbits, void *__restrict__ keys, u32 *__restrict__ vals,
-							     u32 *__restrict__ zero, u32 nzero)
+							     u32 *__restrict__ zero, u32 nzero,
+							     const u32 *__restrict__ nchunks_dev, u32 launch_cap)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	for (u32 z = i; z < nzero; z += gridDim.x * WL_THREADS)
 		zero[z] = 0; // run starts/ends per light cell, written after the sort
 	if (i >= n)
 		return;
+	if (nchunks_dev) { // the chunk count never went to the host (UGRT_CHUNKS_ON_DEVICE): same rule, here
+		nchunks = *nchunks_dev;
+		const u32 lim = nchunks < launch_cap ? nchunks : launch_cap;
+		traced = launch_cap == 0xFFFFFFFFu ? nchunks : (lim ? lim - 1u : 0u);
+	}
 	const u32 M = traced < nchunks ? prefix[traced] : n;
 	const u32 pixel = d_map[i];
 	u32 cell = d_map[n + i];
@@ -1194,11 +1200,18 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// which chunks get traced: the reference launches nbx*nby blocks, block b
 	// takes chunk b-1 and only blocks b < num_chunks work (light_kernel.cu:76-85)
 	u32 traced;
-	if (ctx->cfg.flags & UGRT_FLAG_SHADOW_ALL_CHUNKS) {
+	const bool on_device = num_chunks == UGRT_CHUNKS_ON_DEVICE; // ugrt_sort_rays(..., NULL) left the count there
+	const u32 launch_cap = (ctx->cfg.flags & UGRT_FLAG_SHADOW_ALL_CHUNKS) ? 0xFFFFFFFFu : (u32)ctx->nbx * (u32)ctx->nby;
+	const u32 *nchunks_dev = nullptr;
+	if (on_device) {
+		if (!ctx->cbase.p)
+			return ugrt_fail(UGRT_EINVAL, "trace_shadow: UGRT_CHUNKS_ON_DEVICE without a ugrt_sort_rays before");
+		nchunks_dev = (const u32 *)ctx->cbase.p + C; // inclusive scan of the chunks per light cell, last entry
+		traced = num_chunks;                          // the keys kernel applies the launch rule itself
+	} else if (launch_cap == 0xFFFFFFFFu) {
 		traced = num_chunks;
 	} else {
-		u32 launch = (u32)ctx->nbx * (u32)ctx->nby;
-		u32 lim = num_chunks < launch ? num_chunks : launch;
+		u32 lim = num_chunks < launch_cap ? num_chunks : launch_cap;
 		traced = lim ? lim - 1 : 0;
 	}
 	ctx->stats[2] = traced;
@@ -1254,14 +1267,14 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if (key64) {
 		hipLaunchKernelGGL(k_shadow_keys<true>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk);
+				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap);
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs64(ctx, (const u64 *)k0, (u64 *)k1, v0, v1, n, 30 + (int)cellbits)))
 			return rc;
 	} else {
 		hipLaunchKernelGGL(k_shadow_keys<false>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk);
+				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap);
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits))))
 			return rc;

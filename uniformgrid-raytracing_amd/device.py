@@ -142,9 +142,19 @@ class Context:
     def prefix_capacity(self):
         return self.npix // 64 + self.light_grid[0] * self.light_grid[1] + 2
 
-    def sort_rays(self, d_map, d_prefix):
+    def sort_rays(self, d_map, d_prefix, deferred=False):
+        """processData.  deferred=True: does not wait for the device; returns CHUNKS_ON_DEVICE, which
+        trace_shadow accepts, and sort_rays_chunks() fetches the number later."""
+        if deferred:
+            check(lib.ugrt_sort_rays(self._h, _ptr(d_map), _ptr(d_prefix), d_prefix.numel(), None))
+            return 0xFFFFFFFF
         n = C.c_uint()
         check(lib.ugrt_sort_rays(self._h, _ptr(d_map), _ptr(d_prefix), d_prefix.numel(), C.byref(n)))
+        return n.value
+
+    def sort_rays_chunks(self):
+        n = C.c_uint()
+        check(lib.ugrt_sort_rays_chunks(self._h, C.byref(n)))
         return n.value
 
     def trace_shadow(self, value, verts, faces, span, offset, t, ray_dir, is_shadowed, d_map, d_prefix, cam_pos,

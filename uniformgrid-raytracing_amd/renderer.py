@@ -106,9 +106,17 @@ class Renderer:
         self.cam_pos = ctx.empty(3, t.float32)
         self.rays = self.active = self.hit_t = self.hit_id = None
         self.reflect_eps = float(reflect_eps)
-        self.num_chunks = 0
+        self._num_chunks = 0
         self.orig = None
         self.aspect = float(np.float32(ctx.width) / np.float32(ctx.height))
+
+    @property
+    def num_chunks(self):
+        """h_numCudaBlocks of the last frame (fetched from the device on first use: the frame loop itself
+        never waits for it)."""
+        if self._num_chunks == 0xFFFFFFFF:
+            self._num_chunks = self.ctx.sort_rays_chunks()
+        return self._num_chunks
 
     # Model::init_orig_list, scene.h:336
     def init_orig_list(self, size, offset):
@@ -159,9 +167,9 @@ class Renderer:
             ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
             ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
             lvalue, lspan, loffset, _ = ctx.grid_ptrs(GRID_SPHERICAL)
-            self.num_chunks = ctx.sort_rays(self.d_map, self.prefix)
+            self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
             ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
-                             self.d_map, self.prefix, self.cam_pos, self.num_chunks)
+                             self.d_map, self.prefix, self.cam_pos, self._num_chunks)
         if not shade:
             return
         if reflect:
@@ -238,12 +246,12 @@ class Renderer:
         ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
         if shadows:
             ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
-            self.num_chunks = ctx.sort_rays(self.d_map, self.prefix)
+            self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
             light_grid_recorded.wait()
             main.wait_event(ev_light_grid)
             lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
             ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
-                             self.d_map, self.prefix, self.cam_pos, self.num_chunks)
+                             self.d_map, self.prefix, self.cam_pos, self._num_chunks)
         err = self._done.get()  # the side stream's work is enqueued
         if err is not None:
             raise err

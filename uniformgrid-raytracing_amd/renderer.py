@@ -104,6 +104,10 @@ class Renderer:
         self.prefix = ctx.empty(ctx.prefix_capacity(), t.int32)
         self.image = t.zeros(3 * N, dtype=t.uint8, device=ctx.device)
         self.cam_pos = ctx.empty(3, t.float32)
+        # pinned staging for d_cam_position: a pageable-memory copy would make the host wait for the whole
+        # previous frame before it may enqueue the next one (the grid build's read-back, which follows in stream
+        # order, guarantees the staging buffer is free again by the next frame)
+        self._cam_pos_host = t.empty(3, dtype=t.float32).pin_memory()
         self.rays = self.active = self.hit_t = self.hit_id = None
         self.reflect_eps = float(reflect_eps)
         self._num_chunks = 0
@@ -153,7 +157,8 @@ class Renderer:
         ctx.set_light_position(setup.shading_light)
         cam = make_camera(setup.camera, setup.fovy, self.aspect)
         # main.cu:128 d_cam_position <- worldori ; fillCoordinatesData
-        self.cam_pos.copy_(t.from_numpy(cam.worldori[:3].copy()), non_blocking=False)
+        self._cam_pos_host.copy_(t.from_numpy(cam.worldori[:3].copy()))
+        self.cam_pos.copy_(self._cam_pos_host, non_blocking=True)
         ctx.upload_camera(cam.camcoords)
         # build_frustum_grid
         ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
@@ -234,7 +239,8 @@ class Renderer:
             # main stream: the camera pass
             ctx.set_light_position(setup.shading_light)
             cam = make_camera(setup.camera, setup.fovy, self.aspect)
-            self.cam_pos.copy_(t.from_numpy(cam.worldori[:3].copy()), non_blocking=False)
+            self._cam_pos_host.copy_(t.from_numpy(cam.worldori[:3].copy()))
+            self.cam_pos.copy_(self._cam_pos_host, non_blocking=True)
             ctx.upload_camera(cam.camcoords)
             ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
             value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)

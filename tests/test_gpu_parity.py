@@ -535,6 +535,38 @@ def test_degenerate_triangles(ugrt, O, torch):
     assert (want["mat_ids"] >= 0).sum() > 1000
 
 
+def test_deferred_chunk_count_and_options(ugrt, O, torch):
+    """ugrt_sort_rays without the read-back: the count fetched later equals the synchronous one, and the shadow
+    tracer fed UGRT_CHUNKS_ON_DEVICE produces the same flags, in the reference's launch-capped mode and with
+    every chunk traced; ugrt_ctx_set_option accepts its key and rejects others."""
+    s = scene(ugrt, "hall")
+    W, H, lg = 256, 256, (64, 64)
+    setup = setup_for(ugrt, s, "ref")
+    for flags in (0, ugrt.FLAG_SHADOW_ALL_CHUNKS):
+        ctx, r = make(ugrt, s, W, H, lg, flags=flags)
+        r.display(setup, shadows=True)  # the renderer defers the count
+        ctx.synchronize()
+        flags_deferred = r.is_shadowed.cpu().numpy().copy()
+        n_deferred = r.num_chunks
+        # the same stages with the count on the host
+        lvalue, lspan, loffset, _ = ctx.grid_ptrs(ugrt.GRID_SPHERICAL)
+        ctx.map_rays_to_light(r.t, r.dir, r.d_map, r.cam_pos, np.float32(np.pi), np.float32(np.pi))
+        n_sync = ctx.sort_rays(r.d_map, r.prefix)
+        assert n_sync == n_deferred == ctx.sort_rays_chunks() and 0 < n_sync < 0xFFFFFFFF
+        r.is_shadowed.zero_()
+        ctx.trace_shadow(lvalue, r.d_verts, r.d_faces, lspan, loffset, r.t, r.dir, r.is_shadowed, r.d_map, r.prefix,
+                         r.cam_pos, n_sync)
+        ctx.synchronize()
+        np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), flags_deferred)
+        assert flags_deferred.sum() > 0
+    ctx.set_option("dda_rays_per_wave", 64)
+    ctx.set_option("dda_rays_per_wave", 0)
+    with pytest.raises(ugrt.UgrtError):
+        ctx.set_option("dda_rays_per_wave", 65)
+    with pytest.raises(ugrt.UgrtError):
+        ctx.set_option("no_such_option", 1)
+
+
 def test_error_paths(ugrt, torch):
     with pytest.raises(ugrt.UgrtError) as e:
         ugrt.Context(250, 256)

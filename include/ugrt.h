@@ -173,9 +173,13 @@ int ugrt_rot_cos_sin(float rot, float *c, float *s);
 /* ---- device: context --------------------------------------------------- */
 int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cfg);
 int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
-/* launch-shape options of this context; none changes a result.  key "dda_rays_per_wave": 1..64 secondary
- * rays per wave of ugrt_trace_dda (default 32: fastest when the traversal has the GPU to itself; 64 halves its
- * waves, which a context that runs beside another stream's kernels is better off with); 0 = default. */
+/* launch-shape options of this context; none changes a result; value < 0 restores the default.  Keys:
+ * "dda_kernel" 0 = beam kernel (rays of a wave share the work inside a cell), 1 = per-ray kernel;
+ * "dda_rays_per_wave" 1..64 (0 = default); "dda_coop", "dda_cull_min" list lengths from which a lone ray's
+ * cell is tested by the whole wave / a shared cell is culled before the exact tests; "primary_seg" triangles
+ * per primary work item; "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits",
+ * "shadow_key64" shape the shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix
+ * sort instead of the built-in one. */
 int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value);
 int ugrt_ctx_synchronize(ugrt_ctx *ctx);
 void ugrt_ctx_destroy(ugrt_ctx *ctx);
@@ -278,6 +282,12 @@ int ugrt_prof_get(ugrt_ctx *ctx, int stage, double *ms_total, int *launches);
  * tests, [7] shadow exact pass: candidates staged (candidate pairs x 64-ray sub-groups);
  * with UGRT_FLAG_COUNT_WORK also [3] DDA candidates tested, [4] DDA cells visited, [5] DDA active rays */
 int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8]);
+/* how the beam kernel of ugrt_trace_dda shared its work in the last counting launch (UGRT_FLAG_COUNT_WORK):
+ * [0] wave iterations (4 steps each), [1] cell groups processed, [2] rays in those groups, [3] cull batches,
+ * [4] triangles culled against a ray bundle, [5] exact-test rounds (one broadcast triangle), [6] rays that ran
+ * those rounds, [7] exact tests of lone rays, [8..23] waves by log2(shader cycles / 4096), [24] sum and
+ * [25] maximum of the waves' cycles; entries past n are not written, entries past 25 are 0 */
+int ugrt_stats_dda(ugrt_ctx *ctx, unsigned long long *stats, int n);
 
 #ifdef __cplusplus
 }

@@ -1,21 +1,78 @@
-"""Sweep the DDA tunables on the bench workload (one process per setting is not needed: read per call)."""
-import os, sys, time
+"""DDA kernels on the bench workload, alone on the GPU: beam kernel against the per-ray kernel of round 1
+(identical results checked), launch-shape sweep, and the beam kernel's work-sharing counters.
+
+    python tools/dda_sweep.py [--quick] [--out FILE.json]
+"""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, ugrt, bench
+
+quick = "--quick" in sys.argv
+out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
 s = bench.load_scene(ugrt, 'crash', 1.0, 0)
 setup = ugrt.FrameSetup.from_scene(s)
-ctx = ugrt.Context(1920, 1080, light_grid=(128, 128), flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, uniform_dims=(128, 128, 64))
-r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
-for _ in range(3):
-    r.display(setup, reflect=True)
-ctx.synchronize()
+dims = (128, 128, 64)
+
+
+def make(flags):
+    ctx = ugrt.Context(1920, 1080, light_grid=(128, 128), flags=flags, uniform_dims=dims)
+    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    for _ in range(2):
+        r.display(setup, reflect=True)
+    ctx.synchronize()
+    return ctx, r
+
+
+ctx, r = make(ugrt.FLAG_SHADOW_ALL_CHUNKS)
 uvalue, uspan, uoffset, _ = ctx.grid_ptrs(ugrt.GRID_UNIFORM)
-ctx.prof_enable(True)
-for rpw in (4, 8, 16, 32, 64):
-    for coop in (4, 8, 16, 32, 1 << 30):
-        os.environ["UGRT_DDA_RPW"], os.environ["UGRT_DDA_COOP"] = str(rpw), str(coop)
-        ctx.prof_reset()
-        for _ in range(5):
-            ctx.trace_dda(uvalue, uspan, uoffset, r.d_verts, r.d_faces, r.rays, r.active, r.hit_t, r.hit_id)
-        p = ctx.prof_get()["trace_dda"]
-        print("rpw %2d coop %10d : %.3f ms" % (rpw, coop, p[0] / p[1]), flush=True)
+
+
+def run(ctx, r, n=5):
+    uvalue, uspan, uoffset, _ = ctx.grid_ptrs(ugrt.GRID_UNIFORM)
+    ctx.trace_dda(uvalue, uspan, uoffset, r.d_verts, r.d_faces, r.rays, r.active, r.hit_t, r.hit_id)
+    ctx.synchronize()
+    ctx.prof_enable(True, stages=("trace_dda",))
+    ctx.prof_reset()
+    for _ in range(n):
+        ctx.trace_dda(uvalue, uspan, uoffset, r.d_verts, r.d_faces, r.rays, r.active, r.hit_t, r.hit_id)
+    p = ctx.prof_get()["trace_dda"]
+    ctx.prof_enable(False)
+    return p[0] / p[1]
+
+
+res = {"rows": []}
+ctx.set_option("dda_kernel", 1)
+ctx.set_option("dda_rays_per_wave", 32)
+ms_ray = run(ctx, r)
+ref_t, ref_id = r.hit_t.clone(), r.hit_id.clone()
+print("per-ray kernel, 32 rays per wave: %.3f ms" % ms_ray, flush=True)
+res["per_ray_rpw32_ms"] = ms_ray
+ctx.set_option("dda_kernel", 0)
+for rpw in (16, 32, 64):
+    for cull_min in ((8,) if quick else (8, 1 << 30)):
+        for coop in (8,):
+            ctx.set_option("dda_rays_per_wave", rpw)
+            ctx.set_option("dda_cull_min", cull_min)
+            ctx.set_option("dda_coop", coop)
+            r.hit_t.fill_(7.0)
+            r.hit_id.fill_(7)
+            ms = run(ctx, r)
+            same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
+            print("beam rpw %2d cull_min %10d coop %2d : %.3f ms  identical=%s" % (rpw, cull_min, coop, ms, same), flush=True)
+            res["rows"].append({"rpw": rpw, "cull_min": cull_min, "coop": coop, "ms": ms, "identical": same})
+# work counters
+cctx, cr = make(ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_COUNT_WORK)
+for k in (0, 1):
+    cctx.set_option("dda_kernel", k)
+    uv, us, uo, _ = cctx.grid_ptrs(ugrt.GRID_UNIFORM)
+    cctx.trace_dda(uv, us, uo, cr.d_verts, cr.d_faces, cr.rays, cr.active, cr.hit_t, cr.hit_id)
+    st = cctx.stats()
+    print("kernel %d: tests %d cells %d rays %d" % (k, st[3], st[4], st[5]), flush=True)
+    res["work_kernel%d" % k] = {"tests": st[3], "cells": st[4], "rays": st[5]}
+    if k == 0:
+        d = cctx.stats_dda()
+        print("beam sharing:", d, flush=True)
+        res["beam_sharing"] = d
+        res["algorithmic_bytes"] = 48 * st[5] + 8 * st[4] + 52 * st[3]
+if out:
+    json.dump(res, open(out, "w"), indent=1)

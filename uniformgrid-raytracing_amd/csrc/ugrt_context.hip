@@ -76,6 +76,8 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 	ugrt_ctx *ctx = new ugrt_ctx();
 	ctx->cfg = *cfg;
 	ctx->device = device;
+	for (int i = 0; i < UGRT_OPT_COUNT; i++)
+		ctx->opt[i] = -1;
 	ctx->nbx = nbx;
 	ctx->nby = nby;
 	ctx->p0 = cfg->row_begin * 8 * cfg->width;
@@ -87,7 +89,7 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 	ctx->cam.nby = nby;
 	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 32 * sizeof(u32), hipHostMallocDefault);
 	if (e == hipSuccess)
-		e = hipMalloc((void **)&ctx->d_small, (32 + 100) * sizeof(u32));
+		e = hipMalloc((void **)&ctx->d_small, UGRT_DSMALL_WORDS * sizeof(u32));
 	if (e != hipSuccess) {
 		ugrt_ctx_destroy(ctx);
 		return ugrt_fail(UGRT_EHIP, "ctx_create: %s", hipGetErrorString(e));
@@ -173,16 +175,30 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	delete ctx;
 }
 
+// option keys in the order of the UGRT_OPT_* enum, with their accepted ranges
+static const struct {
+	const char *key;
+	int lo, hi;
+} k_opt[UGRT_OPT_COUNT] = {
+	{ "dda_rays_per_wave", 0, 64 }, { "dda_coop", 1, 1 << 30 },     { "dda_kernel", 0, 1 },
+	{ "dda_cull_min", 1, 1 << 30 }, { "primary_seg", 64, 1 << 20 }, { "shadow_beam", 64, 8192 },
+	{ "shadow_xseg", 64, 1 << 20 }, { "shadow_sizebits", 0, 8 },    { "shadow_itemsort", 0, 1 },
+	{ "shadow_mbits", 1, 24 },      { "shadow_key64", 0, 1 },       { "sort_library", 0, 1 },
+};
+
 extern "C" int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value)
 {
 	if (!ctx || !key)
 		return ugrt_fail(UGRT_EINVAL, "ctx_set_option: null argument");
-	if (strcmp(key, "dda_rays_per_wave") == 0) {
-		if (value < 0 || value > 64)
-			return ugrt_fail(UGRT_EINVAL, "ctx_set_option: dda_rays_per_wave %d outside [0,64]", value);
-		ctx->opt_dda_rpw = value;
-		return UGRT_OK;
-	}
+	for (int i = 0; i < UGRT_OPT_COUNT; i++)
+		if (strcmp(key, k_opt[i].key) == 0) {
+			if (value >= 0 && (value < k_opt[i].lo || value > k_opt[i].hi))
+				return ugrt_fail(UGRT_EINVAL, "ctx_set_option: %s %d outside [%d,%d]", key, value, k_opt[i].lo,
+						 k_opt[i].hi);
+			// 0 keeps meaning "default" for the rays-per-wave option of version 100
+			ctx->opt[i] = (value < 0 || (i == UGRT_OPT_DDA_RPW && value == 0)) ? -1 : value;
+			return UGRT_OK;
+		}
 	return ugrt_fail(UGRT_EINVAL, "ctx_set_option: unknown key '%s'", key);
 }
 
@@ -215,7 +231,7 @@ __global__ void k_store_table(TexArg t, float *dst)
 		dst[i] = t.v[i];
 }
 
-float *ugrt_ctx_tex(ugrt_ctx *ctx) { return (float *)(ctx->d_small + 32); }
+float *ugrt_ctx_tex(ugrt_ctx *ctx) { return (float *)(ctx->d_small + UGRT_DSMALL_TEX); }
 
 // per_frame_funcs.h:18-43 fillCoordinatesData (+ setDirectionTexture :161)
 extern "C" int ugrt_upload_camera(ugrt_ctx *ctx, const float camcoords[64])

@@ -18,6 +18,23 @@ struct CamBlock {
 	int W, H, nbx, nby;
 };
 
+// launch-shape options (ugrt_ctx_set_option): none changes a result
+enum {
+	UGRT_OPT_DDA_RPW = 0,      // "dda_rays_per_wave"
+	UGRT_OPT_DDA_COOP,         // "dda_coop": list length from which a lone ray's cell is tested by the whole wave
+	UGRT_OPT_DDA_KERNEL,       // "dda_kernel": 0 = beam kernel, 1 = per-ray kernel of round 1
+	UGRT_OPT_DDA_CULL_MIN,     // "dda_cull_min": list length from which a shared cell is culled before the exact tests
+	UGRT_OPT_PRIMARY_SEG,      // "primary_seg"
+	UGRT_OPT_SHADOW_BEAM,      // "shadow_beam"
+	UGRT_OPT_SHADOW_XSEG,      // "shadow_xseg"
+	UGRT_OPT_SHADOW_SIZEBITS,  // "shadow_sizebits"
+	UGRT_OPT_SHADOW_ITEMSORT,  // "shadow_itemsort"
+	UGRT_OPT_SHADOW_MBITS,     // "shadow_mbits"
+	UGRT_OPT_SHADOW_KEY64,     // "shadow_key64"
+	UGRT_OPT_SORT_LIBRARY,     // "sort_library": 1 = rocPRIM radix sort instead of the built-in one
+	UGRT_OPT_COUNT
+};
+
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
@@ -35,6 +52,14 @@ struct Grid {
 	float ug[12] = { 0 }; // uniform grid: lo[3], cell[3], inv cell[3]
 	bool valid = false;
 };
+
+// layout of ugrt_ctx::d_small (u32 words): [0,32) totals and tracer counters, [32,132) the 5x5x4 direction
+// table, [132, 132 + 64) the DDA's work counters (u64)
+#define UGRT_DSMALL_TICKET 8
+#define UGRT_DSMALL_TEX 32
+#define UGRT_DSMALL_DDA 132
+#define UGRT_DSMALL_WORDS (132 + 104)
+#define UGRT_DDA_STATS 46
 
 struct ProfPair {
 	hipEvent_t a, b;
@@ -67,13 +92,14 @@ struct ugrt_ctx {
 	DevBuf citem;                                        // shadow tracer: light cell of every cull item
 	DevBuf sitem;                                        // shadow tracer: exact-pass item list (segment, beam|sub) x2
 	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
-	u32 *d_small = nullptr;       // 16 u32 of device scratch (totals)
+	u32 *d_small = nullptr;       // device scratch words (totals, counters, the direction table)
 	unsigned prof_mask = 0; // bit s = stage s is timed
 	unsigned chunk_capacity = 0; // prefix_capacity of the last ugrt_sort_rays
-	int opt_dda_rpw = 0;    // ugrt_ctx_set_option "dda_rays_per_wave" (0 = default)
+	int opt[UGRT_OPT_COUNT];     // ugrt_ctx_set_option; -1 = the built-in default
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;
 	unsigned long long stats[8] = { 0 };
+	unsigned long long dda_stats[UGRT_DDA_STATS] = { 0 }; // ugrt_stats_dda
 };
 
 #define UGRT_HIP(call)                                                                            \

@@ -1,0 +1,273 @@
+// ugrt_packet.h -- device helpers shared by the tracers (ugrt_trace.hip, ugrt_dda.hip): XCD-aware work
+// placement, triangle records, conservative packet culls, cross-lane primitives.
+#ifndef UGRT_PACKET_H
+#define UGRT_PACKET_H
+
+#include "ugrt_dev.h"
+
+#define TRI_STRIDE 12     // floats per staged triangle (9 used, 48 B: ds_read_b128 x3)
+#define WL_THREADS 256
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Work lists
+// are ordered so that neighbours share data (same cell, same triangle batch, same beam), so the
+// persistent waves take CONTIGUOUS slices per XCD: logical id = (b % 8) * (grid/8) + b / 8.
+// Placement only affects speed, never results.
+__device__ __forceinline__ u32 d_xcd_block()
+{
+	const u32 g = gridDim.x, b = blockIdx.x;
+	return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
+}
+
+// ---------------------------------------------------------------------------
+// Packet culling.  All 64 rays of a work item share one origin (the eye, or the light), so for
+// a triangle {tvec, e1, e2} the three Moller-Trumbore numerators are LINEAR in the direction d:
+//   det = d.(e2 x e1)   A = u*det = d.(e2 x tvec)   B = v*det = d.(tvec x e1)
+// A hit needs A/det >= 0, B/det >= 0, (A+B)/det <= 1.  Interval arithmetic over the bounding box
+// of the item's directions shows "no lane can pass" for most triangles of a cell list (the
+// lists come from clamped bounding boxes); only survivors get the per-lane test.
+// One LANE culls one TRIANGLE, so a batch of 64 is culled for the price of one per-lane test.
+// The margins (2^-16 relative to the operand magnitudes, against rounding errors of ~2^-22)
+// make the cull strictly conservative: a culled triangle fails the exact float test of
+// intersectTriUV / intersectTri on every lane, so results do not change by a bit.
+// ---------------------------------------------------------------------------
+struct DirBox {
+	float lo[3], hi[3];
+};
+
+__device__ __forceinline__ float d_wave_min(float v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		v = fminf(v, __shfl_xor(v, m));
+	return v;
+}
+__device__ __forceinline__ float d_wave_max(float v)
+{
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		v = fmaxf(v, __shfl_xor(v, m));
+	return v;
+}
+
+// box of the directions of the lanes with `valid`; other lanes do not contribute
+__device__ __forceinline__ DirBox d_dir_box(const float *d, bool valid)
+{
+	DirBox bx;
+	const float inf = __builtin_huge_valf();
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		bx.lo[k] = d_wave_min(valid ? d[k] : inf);
+		bx.hi[k] = d_wave_max(valid ? d[k] : -inf);
+	}
+	return bx;
+}
+
+__device__ __forceinline__ void d_interval_dot(const float *n, const DirBox &bx, float *fmin, float *fmax)
+{
+#pragma clang fp contract(fast)
+	float mn = 0.0f, mx = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		float p = n[k] * bx.lo[k], q = n[k] * bx.hi[k];
+		mn += fminf(p, q);
+		mx += fmaxf(p, q);
+	}
+	*fmin = mn;
+	*fmax = mx;
+}
+
+// true = no direction inside the box can hit the triangle
+__device__ __forceinline__ bool d_cull(const float *tv, const float *e1, const float *e2, const DirBox &bx)
+{
+#ifdef UGRT_DEBUG_CULL_ALL
+	return (tv[0] + tv[1] + tv[2] + e1[0] + e1[1] + e1[2] + e2[0] + e2[1] + e2[2]) != 12345.678f;
+#endif
+#pragma clang fp contract(fast)
+	float nA[3], nB[3], nD[3], nC[3];
+	D_CROSS(nA, e2, tv);
+	D_CROSS(nB, tv, e1);
+	D_CROSS(nD, e2, e1);
+	const float a = fmaxf(fmaxf(fabsf(tv[0]), fabsf(tv[1])), fabsf(tv[2]));
+	const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
+	const float c = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
+	const float K = 6.0f / 65536.0f;
+	const float mA = fmaxf(K * a * c, 1e-25f), mB = fmaxf(K * a * b, 1e-25f), mD = fmaxf(K * b * c, 1e-25f);
+	float Dmin, Dmax, lo, hi;
+	d_interval_dot(nD, bx, &Dmin, &Dmax);
+	if (!(Dmax < 1e15f && Dmin > -1e15f))
+		return false;
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		nC[k] = nA[k] + nB[k] - nD[k];
+	if (Dmin > mD) { // det > 0 on every lane
+		d_interval_dot(nA, bx, &lo, &hi);
+		if (hi < -mA)
+			return true; // u < 0
+		d_interval_dot(nB, bx, &lo, &hi);
+		if (hi < -mB)
+			return true; // v < 0
+		d_interval_dot(nC, bx, &lo, &hi);
+		return lo > mA + mB + mD; // u + v > 1
+	}
+	if (Dmax < -mD) { // det < 0 on every lane
+		d_interval_dot(nA, bx, &lo, &hi);
+		if (lo > mA)
+			return true;
+		d_interval_dot(nB, bx, &lo, &hi);
+		if (lo > mB)
+			return true;
+		d_interval_dot(nC, bx, &lo, &hi);
+		return hi < -(mA + mB + mD);
+	}
+	return false;
+}
+
+// one triangle as {origin - v0, v1 - v0, v2 - v0}: from the 48-B record, or gathered as the
+// reference does (trace_kernel.cu:151-175) when the caller's arrays are not the ones last built
+template <bool REC>
+__device__ __forceinline__ void d_load_triangle(const float4 *__restrict__ rec, const float *__restrict__ verts,
+						const int *__restrict__ tris, u32 face, float ox, float oy, float oz,
+						float *t9)
+{
+	if (REC) {
+		const float4 a = rec[face * 3 + 0], b = rec[face * 3 + 1], c = rec[face * 3 + 2];
+		t9[0] = ox - a.x;
+		t9[1] = oy - a.y;
+		t9[2] = oz - a.z;
+		t9[3] = a.w;
+		t9[4] = b.x;
+		t9[5] = b.y;
+		t9[6] = b.z;
+		t9[7] = b.w;
+		t9[8] = c.x;
+	} else {
+		d_stage_triangle(verts, tris, face, ox, oy, oz, t9);
+	}
+}
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ u32 d_rank_in_mask(unsigned long long mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+
+// The same test with the triangle's part hoisted (it is reused for several boxes) and the box given as
+// centre +- half width: f(d) = n.d ranges over n.c -+ sum_k |n_k| r_k.
+struct CullTri {
+	float nA[3], nB[3], nC[3], nD[3];
+	float mA, mB, mD;
+};
+struct CBox {
+	float c[3], r[3];
+};
+
+// (The cull is outside the numeric contract: it only has to be conservative, and its margins are 2^6
+// times the rounding error, so its dot products may contract to FMAs; the exact tests never do.)
+__device__ __forceinline__ CullTri d_cull_prep(const float *tv, const float *e1, const float *e2)
+{
+#pragma clang fp contract(fast)
+	CullTri t;
+	D_CROSS(t.nA, e2, tv);
+	D_CROSS(t.nB, tv, e1);
+	D_CROSS(t.nD, e2, e1);
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		t.nC[k] = t.nA[k] + t.nB[k] - t.nD[k];
+	const float a = fmaxf(fmaxf(fabsf(tv[0]), fabsf(tv[1])), fabsf(tv[2]));
+	const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
+	const float c = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
+	const float K = 6.0f / 65536.0f;
+	t.mA = fmaxf(K * a * c, 1e-25f);
+	t.mB = fmaxf(K * a * b, 1e-25f);
+	t.mD = fmaxf(K * b * c, 1e-25f);
+	return t;
+}
+
+__device__ __forceinline__ bool d_cull_cr(const CullTri &t, const CBox &bx)
+{
+#pragma clang fp contract(fast)
+	const float Dm = t.nD[0] * bx.c[0] + t.nD[1] * bx.c[1] + t.nD[2] * bx.c[2];
+	const float Dr = fabsf(t.nD[0]) * bx.r[0] + fabsf(t.nD[1]) * bx.r[1] + fabsf(t.nD[2]) * bx.r[2];
+	if (!(Dm + Dr < 1e15f && Dm - Dr > -1e15f))
+		return false;
+	const float Am = t.nA[0] * bx.c[0] + t.nA[1] * bx.c[1] + t.nA[2] * bx.c[2];
+	const float Ar = fabsf(t.nA[0]) * bx.r[0] + fabsf(t.nA[1]) * bx.r[1] + fabsf(t.nA[2]) * bx.r[2];
+	const float Bm = t.nB[0] * bx.c[0] + t.nB[1] * bx.c[1] + t.nB[2] * bx.c[2];
+	const float Br = fabsf(t.nB[0]) * bx.r[0] + fabsf(t.nB[1]) * bx.r[1] + fabsf(t.nB[2]) * bx.r[2];
+	const float Cm = t.nC[0] * bx.c[0] + t.nC[1] * bx.c[1] + t.nC[2] * bx.c[2];
+	const float Cr = fabsf(t.nC[0]) * bx.r[0] + fabsf(t.nC[1]) * bx.r[1] + fabsf(t.nC[2]) * bx.r[2];
+	const float mC = t.mA + t.mB + t.mD;
+	if (Dm - Dr > t.mD) // det > 0 for every direction of the box
+		return (Am + Ar < -t.mA) || (Bm + Br < -t.mB) || (Cm - Cr > mC);
+	if (Dm + Dr < -t.mD) // det < 0
+		return (Am - Ar > t.mA) || (Bm - Br > t.mB) || (Cm + Cr < -mC);
+	return false;
+}
+
+__device__ __forceinline__ float d_readlane(float v, int l)
+{
+	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+
+// persistent launches: 256 CUs x 8 single-wave workgroups per SIMD-quad
+static inline int launch_blocks_for(u32 upper)
+{
+	// 256 CUs x 8 single-wave workgroups per SIMD-quad; waves are persistent
+	u32 g = 256u * 32u;
+	if (upper < g)
+		g = upper ? upper : 1u;
+	return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// Wave reductions on the DPP path (row_shr 1/2/4/8, row_bcast 15/31: ~4 VALU instructions per step).
+// __shfl_xor compiles to ds_bpermute_b32 on gfx950, i.e. six dependent trips through the LDS crossbar
+// per reduction.  `v` of lanes that must not contribute is the identity (+-inf, ~0).  The result is
+// uniform (read from lane 63).
+// ---------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int d_dpp_i(int old, int src)
+{
+	return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+struct DOpMin {
+	template <typename T>
+	__device__ __forceinline__ static T op(T a, T b) { return b < a ? b : a; }
+};
+struct DOpMax {
+	template <typename T>
+	__device__ __forceinline__ static T op(T a, T b) { return b > a ? b : a; }
+};
+__device__ __forceinline__ int d_as_int(int v) { return v; }
+__device__ __forceinline__ int d_as_int(float v) { return __float_as_int(v); }
+__device__ __forceinline__ void d_from_int(int i, int *v) { *v = i; }
+__device__ __forceinline__ void d_from_int(int i, float *v) { *v = __int_as_float(i); }
+
+template <typename OP, typename T>
+__device__ __forceinline__ T d_wave_reduce(T v, T identity)
+{
+	const int id = d_as_int(identity);
+	T o;
+	d_from_int(d_dpp_i<0x111>(id, d_as_int(v)), &o); // row_shr:1
+	v = OP::op(v, o);
+	d_from_int(d_dpp_i<0x112>(id, d_as_int(v)), &o); // row_shr:2
+	v = OP::op(v, o);
+	d_from_int(d_dpp_i<0x114>(id, d_as_int(v)), &o); // row_shr:4
+	v = OP::op(v, o);
+	d_from_int(d_dpp_i<0x118>(id, d_as_int(v)), &o); // row_shr:8: lane 15 of every row holds the row's result
+	v = OP::op(v, o);
+	d_from_int(d_dpp_i<0x142, 0xA>(id, d_as_int(v)), &o); // row_bcast:15 into rows 1 and 3
+	v = OP::op(v, o);
+	d_from_int(d_dpp_i<0x143, 0xC>(id, d_as_int(v)), &o); // row_bcast:31 into rows 2 and 3
+	v = OP::op(v, o);
+	T r;
+	d_from_int(__builtin_amdgcn_readlane(d_as_int(v), 63), &r);
+	return r;
+}
+__device__ __forceinline__ float d_wave_fmin(float v) { return d_wave_reduce<DOpMin>(v, __builtin_huge_valf()); }
+__device__ __forceinline__ float d_wave_fmax(float v) { return d_wave_reduce<DOpMax>(v, -__builtin_huge_valf()); }
+__device__ __forceinline__ int d_wave_imin(int v) { return d_wave_reduce<DOpMin>(v, 0x7FFFFFFF); }
+__device__ __forceinline__ int d_wave_imax(int v) { return d_wave_reduce<DOpMax>(v, (int)0x80000000); }
+
+#endif

@@ -42,11 +42,7 @@ int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n)
 int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
 			 int end_bit)
 {
-	static const bool use_library = [] {
-		const char *e = getenv("UGRT_SORT");
-		return e && strcmp(e, "rocprim") == 0;
-	}();
-	if (use_library || n > ((size_t)1 << 30))
+	if (ctx->opt[UGRT_OPT_SORT_LIBRARY] == 1 || n > ((size_t)1 << 30))
 		return ugrt_prim_sort_pairs_rocprim(ctx, kin, kout, vin, vout, n, end_bit);
 	return ugrt_sort_pairs_u32(ctx, kin, kout, vin, vout, n, end_bit);
 }

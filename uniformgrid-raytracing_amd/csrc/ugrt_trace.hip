@@ -16,20 +16,8 @@
 // over the work list, whose length stays on the device.
 #include <cstdlib>
 
-#include "ugrt_dev.h"
+#include "ugrt_packet.h"
 
-#define TRI_STRIDE 12     // floats per staged triangle (9 used, 48 B: ds_read_b128 x3)
-#define WL_THREADS 256
-
-// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Work lists
-// are ordered so that neighbours share data (same cell, same triangle batch, same beam), so the
-// persistent waves take CONTIGUOUS slices per XCD: logical id = (b % 8) * (grid/8) + b / 8.
-// Placement only affects speed, never results.
-__device__ __forceinline__ u32 d_xcd_block()
-{
-	const u32 g = gridDim.x, b = blockIdx.x;
-	return (g & 7u) ? b : (b & 7u) * (g >> 3) + (b >> 3);
-}
 
 struct WItem {
 	u32 cell;  // primary: screen cell; shadow: chunk index
@@ -89,11 +77,6 @@ struct PrimaryOut {
 // trace_kernel.cu:56-82 isWithin + :230-267 epilogue for one pixel.
 // `ref` = index into value_list of the nearest accepted triangle, ~0u = none.
 template <bool REC>
-__device__ __forceinline__ void d_load_triangle(const float4 *__restrict__ rec, const float *__restrict__ verts,
-						const int *__restrict__ tris, u32 face, float ox, float oy, float oz,
-						float *t9);
-
-template <bool REC>
 __device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const PrimaryOut &o, int pixelID,
 					       const float *dir, float oldt, u32 ref,
 					       const u32 *__restrict__ value_list, const float *__restrict__ verts,
@@ -139,197 +122,6 @@ __device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const Primar
 	o.ray_dir[pixelID * 3 + 0] = dir[0];
 	o.ray_dir[pixelID * 3 + 1] = dir[1];
 	o.ray_dir[pixelID * 3 + 2] = dir[2];
-}
-
-// ---------------------------------------------------------------------------
-// Packet culling.  All 64 rays of a work item share one origin (the eye, or the light), so for
-// a triangle {tvec, e1, e2} the three Moller-Trumbore numerators are LINEAR in the direction d:
-//   det = d.(e2 x e1)   A = u*det = d.(e2 x tvec)   B = v*det = d.(tvec x e1)
-// A hit needs A/det >= 0, B/det >= 0, (A+B)/det <= 1.  Interval arithmetic over the bounding box
-// of the item's directions shows "no lane can pass" for most triangles of a cell list (the
-// lists come from clamped bounding boxes); only survivors get the per-lane test.
-// One LANE culls one TRIANGLE, so a batch of 64 is culled for the price of one per-lane test.
-// The margins (2^-16 relative to the operand magnitudes, against rounding errors of ~2^-22)
-// make the cull strictly conservative: a culled triangle fails the exact float test of
-// intersectTriUV / intersectTri on every lane, so results do not change by a bit.
-// ---------------------------------------------------------------------------
-struct DirBox {
-	float lo[3], hi[3];
-};
-
-__device__ __forceinline__ float d_wave_min(float v)
-{
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-		v = fminf(v, __shfl_xor(v, m));
-	return v;
-}
-__device__ __forceinline__ float d_wave_max(float v)
-{
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-		v = fmaxf(v, __shfl_xor(v, m));
-	return v;
-}
-
-// box of the directions of the lanes with `valid`; other lanes do not contribute
-__device__ __forceinline__ DirBox d_dir_box(const float *d, bool valid)
-{
-	DirBox bx;
-	const float inf = __builtin_huge_valf();
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		bx.lo[k] = d_wave_min(valid ? d[k] : inf);
-		bx.hi[k] = d_wave_max(valid ? d[k] : -inf);
-	}
-	return bx;
-}
-
-__device__ __forceinline__ void d_interval_dot(const float *n, const DirBox &bx, float *fmin, float *fmax)
-{
-#pragma clang fp contract(fast)
-	float mn = 0.0f, mx = 0.0f;
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		float p = n[k] * bx.lo[k], q = n[k] * bx.hi[k];
-		mn += fminf(p, q);
-		mx += fmaxf(p, q);
-	}
-	*fmin = mn;
-	*fmax = mx;
-}
-
-// true = no direction inside the box can hit the triangle
-__device__ __forceinline__ bool d_cull(const float *tv, const float *e1, const float *e2, const DirBox &bx)
-{
-#ifdef UGRT_DEBUG_CULL_ALL
-	return (tv[0] + tv[1] + tv[2] + e1[0] + e1[1] + e1[2] + e2[0] + e2[1] + e2[2]) != 12345.678f;
-#endif
-#pragma clang fp contract(fast)
-	float nA[3], nB[3], nD[3], nC[3];
-	D_CROSS(nA, e2, tv);
-	D_CROSS(nB, tv, e1);
-	D_CROSS(nD, e2, e1);
-	const float a = fmaxf(fmaxf(fabsf(tv[0]), fabsf(tv[1])), fabsf(tv[2]));
-	const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
-	const float c = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
-	const float K = 6.0f / 65536.0f;
-	const float mA = fmaxf(K * a * c, 1e-25f), mB = fmaxf(K * a * b, 1e-25f), mD = fmaxf(K * b * c, 1e-25f);
-	float Dmin, Dmax, lo, hi;
-	d_interval_dot(nD, bx, &Dmin, &Dmax);
-	if (!(Dmax < 1e15f && Dmin > -1e15f))
-		return false;
-#pragma unroll
-	for (int k = 0; k < 3; k++)
-		nC[k] = nA[k] + nB[k] - nD[k];
-	if (Dmin > mD) { // det > 0 on every lane
-		d_interval_dot(nA, bx, &lo, &hi);
-		if (hi < -mA)
-			return true; // u < 0
-		d_interval_dot(nB, bx, &lo, &hi);
-		if (hi < -mB)
-			return true; // v < 0
-		d_interval_dot(nC, bx, &lo, &hi);
-		return lo > mA + mB + mD; // u + v > 1
-	}
-	if (Dmax < -mD) { // det < 0 on every lane
-		d_interval_dot(nA, bx, &lo, &hi);
-		if (lo > mA)
-			return true;
-		d_interval_dot(nB, bx, &lo, &hi);
-		if (lo > mB)
-			return true;
-		d_interval_dot(nC, bx, &lo, &hi);
-		return hi < -(mA + mB + mD);
-	}
-	return false;
-}
-
-// one triangle as {origin - v0, v1 - v0, v2 - v0}: from the 48-B record, or gathered as the
-// reference does (trace_kernel.cu:151-175) when the caller's arrays are not the ones last built
-template <bool REC>
-__device__ __forceinline__ void d_load_triangle(const float4 *__restrict__ rec, const float *__restrict__ verts,
-						const int *__restrict__ tris, u32 face, float ox, float oy, float oz,
-						float *t9)
-{
-	if (REC) {
-		const float4 a = rec[face * 3 + 0], b = rec[face * 3 + 1], c = rec[face * 3 + 2];
-		t9[0] = ox - a.x;
-		t9[1] = oy - a.y;
-		t9[2] = oz - a.z;
-		t9[3] = a.w;
-		t9[4] = b.x;
-		t9[5] = b.y;
-		t9[6] = b.z;
-		t9[7] = b.w;
-		t9[8] = c.x;
-	} else {
-		d_stage_triangle(verts, tris, face, ox, oy, oz, t9);
-	}
-}
-
-// number of set bits of `mask` below this lane
-__device__ __forceinline__ u32 d_rank_in_mask(unsigned long long mask)
-{
-	return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
-}
-
-// The same test with the triangle's part hoisted (it is reused for several boxes) and the box given as
-// centre +- half width: f(d) = n.d ranges over n.c -+ sum_k |n_k| r_k.
-struct CullTri {
-	float nA[3], nB[3], nC[3], nD[3];
-	float mA, mB, mD;
-};
-struct CBox {
-	float c[3], r[3];
-};
-
-// (The cull is outside the numeric contract: it only has to be conservative, and its margins are 2^6
-// times the rounding error, so its dot products may contract to FMAs; the exact tests never do.)
-__device__ __forceinline__ CullTri d_cull_prep(const float *tv, const float *e1, const float *e2)
-{
-#pragma clang fp contract(fast)
-	CullTri t;
-	D_CROSS(t.nA, e2, tv);
-	D_CROSS(t.nB, tv, e1);
-	D_CROSS(t.nD, e2, e1);
-#pragma unroll
-	for (int k = 0; k < 3; k++)
-		t.nC[k] = t.nA[k] + t.nB[k] - t.nD[k];
-	const float a = fmaxf(fmaxf(fabsf(tv[0]), fabsf(tv[1])), fabsf(tv[2]));
-	const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
-	const float c = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
-	const float K = 6.0f / 65536.0f;
-	t.mA = fmaxf(K * a * c, 1e-25f);
-	t.mB = fmaxf(K * a * b, 1e-25f);
-	t.mD = fmaxf(K * b * c, 1e-25f);
-	return t;
-}
-
-__device__ __forceinline__ bool d_cull_cr(const CullTri &t, const CBox &bx)
-{
-#pragma clang fp contract(fast)
-	const float Dm = t.nD[0] * bx.c[0] + t.nD[1] * bx.c[1] + t.nD[2] * bx.c[2];
-	const float Dr = fabsf(t.nD[0]) * bx.r[0] + fabsf(t.nD[1]) * bx.r[1] + fabsf(t.nD[2]) * bx.r[2];
-	if (!(Dm + Dr < 1e15f && Dm - Dr > -1e15f))
-		return false;
-	const float Am = t.nA[0] * bx.c[0] + t.nA[1] * bx.c[1] + t.nA[2] * bx.c[2];
-	const float Ar = fabsf(t.nA[0]) * bx.r[0] + fabsf(t.nA[1]) * bx.r[1] + fabsf(t.nA[2]) * bx.r[2];
-	const float Bm = t.nB[0] * bx.c[0] + t.nB[1] * bx.c[1] + t.nB[2] * bx.c[2];
-	const float Br = fabsf(t.nB[0]) * bx.r[0] + fabsf(t.nB[1]) * bx.r[1] + fabsf(t.nB[2]) * bx.r[2];
-	const float Cm = t.nC[0] * bx.c[0] + t.nC[1] * bx.c[1] + t.nC[2] * bx.c[2];
-	const float Cr = fabsf(t.nC[0]) * bx.r[0] + fabsf(t.nC[1]) * bx.r[1] + fabsf(t.nC[2]) * bx.r[2];
-	const float mC = t.mA + t.mB + t.mD;
-	if (Dm - Dr > t.mD) // det > 0 for every direction of the box
-		return (Am + Ar < -t.mA) || (Bm + Br < -t.mB) || (Cm - Cr > mC);
-	if (Dm + Dr < -t.mD) // det < 0
-		return (Am - Ar > t.mA) || (Bm - Br > t.mB) || (Cm + Cr < -mC);
-	return false;
-}
-
-__device__ __forceinline__ float d_readlane(float v, int l)
-{
-	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
 #define SURV_CAP 128 // survivors buffered in LDS before the per-lane tests run (flush at >= 64)
@@ -490,15 +282,6 @@ __global__ __launch_bounds__(256) void k_resolve_primary(CamBlock cam, const flo
 	d_finish_pixel<REC>(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris, rec);
 }
 
-static int launch_blocks_for(u32 upper)
-{
-	// 256 CUs x 8 single-wave workgroups per SIMD-quad; waves are persistent
-	u32 g = 256u * 32u;
-	if (upper < g)
-		g = upper ? upper : 1u;
-	return (int)g;
-}
-
 // total refs behind a span/offset pair: known for the context's own grids,
 // read back (one 8-byte copy) for arrays that came from elsewhere
 static int refs_of(ugrt_ctx *ctx, const u32 *d_span, const u32 *d_offset, u32 C, u32 *R)
@@ -537,9 +320,7 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	// merged with atomicMin + a resolve pass; cells up to SEG triangles finish inside their one wave.
 	// Every cell of a closed scene carries the few hundred eye-plane-straddling triangles (Q9), so the
 	// cut-off sits above that baseline.
-	u32 SEG = 1024u;
-	if (const char *e = getenv("UGRT_PRIMARY_SEG"))
-		SEG = (u32)atoi(e);
+	u32 SEG = ctx->opt[UGRT_OPT_PRIMARY_SEG] > 0 ? (u32)ctx->opt[UGRT_OPT_PRIMARY_SEG] : 1024u;
 	SEG = SEG < 64u ? 64u : (SEG + 63u) / 64u * 64u;
 	const size_t cap = (size_t)ncell + R / SEG + 1;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->wcount, (size_t)ncell * 4)))
@@ -1258,11 +1039,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// key = (light cell, direction code): 32 bits when the cell index leaves >= 12 bits for the code
 	const u32 cellbits = (u32)bits_of(ncellk);
 	bool key64 = cellbits > 20u;
-	if (const char *e = getenv("UGRT_SHADOW_KEY64"))
-		key64 = key64 || atoi(e) != 0;
+	key64 = key64 || ctx->opt[UGRT_OPT_SHADOW_KEY64] == 1;
 	u32 mbits = 32u - cellbits;
-	if (const char *e = getenv("UGRT_SHADOW_MBITS"))
-		mbits = (u32)atoi(e) < mbits ? (u32)atoi(e) : mbits;
+	if (ctx->opt[UGRT_OPT_SHADOW_MBITS] > 0 && (u32)ctx->opt[UGRT_OPT_SHADOW_MBITS] < mbits)
+		mbits = (u32)ctx->opt[UGRT_OPT_SHADOW_MBITS];
 	mbits = mbits > 24u ? 24u : mbits;
 	if (key64) {
 		hipLaunchKernelGGL(k_shadow_keys<true>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
@@ -1289,16 +1069,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// rays per beam: the cull pass costs (triangles of the cell) x (beams of the cell); the exact pass
 	// re-culls the beam's candidates against each 64-ray sub-group, so its cost barely depends on the
 	// beam size.  ~1000 rays per beam is the measured optimum on the 1 M-triangle scene (tools/beam_sweep.py)
-	u32 beam = 1024u;
-	if (const char *e = getenv("UGRT_SHADOW_BEAM"))
-		beam = (u32)atoi(e);
+	u32 beam = ctx->opt[UGRT_OPT_SHADOW_BEAM] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_BEAM] : 1024u;
 	beam = beam < 64u ? 64u : (beam > 8192u ? 8192u : (beam + 63u) / 64u * 64u);
 	// candidates per exact-pass work item: a 64-ray sub-group stops at the first batch after which all its
 	// rays are flagged, so long items cost little where everything is in shadow; short items bound the
 	// work of a sub-group that stays lit
-	u32 XSEG = 256u;
-	if (const char *e = getenv("UGRT_SHADOW_XSEG"))
-		XSEG = (u32)atoi(e);
+	u32 XSEG = ctx->opt[UGRT_OPT_SHADOW_XSEG] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_XSEG] : 256u;
 	XSEG = XSEG < 64u ? 64u : (XSEG + 63u) / 64u * 64u;
 	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
 			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt, beam, wcnt);
@@ -1318,9 +1094,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			   (u32 *)ctx->citem.p);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
-	u32 sbits = 4u;
-	if (const char *e = getenv("UGRT_SHADOW_SIZEBITS"))
-		sbits = (u32)atoi(e);
+	u32 sbits = ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] >= 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] : 4u;
 	sbits = sbits > 8u ? 8u : sbits;
 	// 2. cull pass -> (beam, triangle) candidate pairs; grows the pair buffer and repeats if it was too small
 	u32 *pcount = ctx->d_small + 20; // right behind the work counters: cleared with them
@@ -1397,9 +1171,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			   (const u32 *)xincl, G, xcap, (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, XSEG,
 			   iseg0, isub0);
 	UGRT_HIP(hipGetLastError());
-	bool item_sort = true;
-	if (const char *e = getenv("UGRT_SHADOW_ITEMSORT"))
-		item_sort = atoi(e) != 0;
+	const bool item_sort = ctx->opt[UGRT_OPT_SHADOW_ITEMSORT] != 0;
 	if (item_sort) {
 		if ((rc = ugrt_prim_sort_pairs(ctx, iseg0, iseg1, isub0, isub1, xcap, 8)))
 			return rc;
@@ -1424,352 +1196,6 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
 				   (const float4 *)ctx->sray.p);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
-	UGRT_HIP(hipGetLastError());
-	return UGRT_OK;
-}
-
-// ---------------------------------------------------------------------------
-// reflection bounce: 3D-DDA through the uniform grid (not in the reference;
-// DESIGN.md A13).  One lane per ray; Amanatides & Woo stepping.
-// ---------------------------------------------------------------------------
-struct DGrid {
-	float lo[3], cs[3], inv[3];
-	int dims[3];
-};
-
-__device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
-{
-	int c = ugrt_floor2i((p - g.lo[k]) * g.inv[k]);
-	return d_clampi(c, 0, g.dims[k] - 1);
-}
-
-#define DDA_AHEAD 4   // cells planned (and their headers fetched) per round trip
-
-__device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long v)
-{
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1) {
-		unsigned long long o = __shfl_xor(v, m);
-		v = o < v ? o : v;
-	}
-	return v;
-}
-
-// One lane per secondary ray, Amanatides & Woo stepping.  A ray's work is a chain of dependent
-// loads (cell header -> triangle id -> record), so the kernel is bound by its LONGEST ray; cells
-// with many triangles (the debris cloud) are therefore tested by the whole wave: the owning
-// lane's ray is broadcast, 64 triangles are tested at once (lane = triangle) and the nearest
-// accepted hit is found with a 64-bit wave min on (t bits << 32 | r).  Sequentially the cell loop
-// keeps the first r with the smallest accepted t (strict <), which is exactly that minimum.
-// default results for every pixel + the list of active secondary rays (order is irrelevant)
-// Each wave owns DDA_PREP_SPAN consecutive pixels and reserves its slots with ONE atomic (a counter
-// bumped once per 64 pixels serialises ~30 k same-address atomics, 0.08 ms at 1080p).
-#define DDA_PREP_SPAN 512
-__global__ __launch_bounds__(256) void k_dda_prepare(const int *__restrict__ active, int p0, int npix,
-						      float *__restrict__ hit_t, int *__restrict__ hit_id,
-						      u32 *__restrict__ list, u32 *__restrict__ count)
-{
-	const int lane = threadIdx.x & 63;
-	const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DDA_PREP_SPAN;
-	if (first >= npix)
-		return;
-	u32 total = 0;
-	unsigned long long flags = 0ull; // bit k: this lane's pixel of round k is active
-#pragma unroll
-	for (int k = 0; k < DDA_PREP_SPAN / 64; k++) {
-		const int i = first + k * 64 + lane;
-		bool a = false;
-		if (i < npix) {
-			a = active[p0 + i] != 0;
-			hit_t[p0 + i] = -1.0f;
-			hit_id[p0 + i] = -2;
-		}
-		flags |= (unsigned long long)a << k;
-		total += (u32)__popcll(__ballot(a));
-	}
-	if (total == 0)
-		return;
-	u32 base = 0;
-	if (lane == 0)
-		base = atomicAdd(count, total);
-	base = __shfl(base, 0);
-#pragma unroll
-	for (int k = 0; k < DDA_PREP_SPAN / 64; k++) {
-		const bool a = (flags >> k) & 1ull;
-		const unsigned long long mask = __ballot(a);
-		if (a)
-			list[base + d_rank_in_mask(mask)] = (u32)(p0 + first + k * 64 + lane);
-		base += (u32)__popcll(mask);
-	}
-}
-
-template <bool COUNT, bool REC>
-__global__ __launch_bounds__(64) void k_trace_dda(DGrid g, const u32 *__restrict__ value_list,
-						   const u32 *__restrict__ span, const u32 *__restrict__ offset,
-						   const float *__restrict__ verts, const int *__restrict__ tris,
-						   const float4 *__restrict__ rec,
-						   const float *__restrict__ rays, const u32 *__restrict__ list,
-						   const u32 *__restrict__ count_p, float *__restrict__ hit_t,
-						   int *__restrict__ hit_id, unsigned long long *__restrict__ counters,
-						   u32 DDA_RPW, u32 DDA_COOP)
-{
-	const int lane = threadIdx.x;
-	const u32 count = *count_p;
-	// DDA_RPW rays per wave: the walk of a ray is a serial chain, and the rays that cross the debris
-	// cloud carry most of the tests, so few rays per wave spreads those chains over the chip while
-	// all 64 lanes still serve the cooperative rounds
-	for (u32 grp = blockIdx.x; grp * DDA_RPW < count; grp += gridDim.x) {
-	const u32 slot = grp * DDA_RPW + (u32)lane;
-	const bool inb = (u32)lane < DDA_RPW && slot < count;
-	const int p = inb ? (int)list[slot] : 0;
-	float res_t = -1.0f;
-	int res_id = -2;
-	u32 n_cells = 0, n_tests = 0;
-	float o[3] = { 0, 0, 0 }, d[3] = { 0, 0, 0 }, tmax[3] = { 0, 0, 0 }, tdelta[3] = { 0, 0, 0 };
-	int c[3] = { 0, 0, 0 }, step[3] = { 0, 0, 0 };
-	float best_t = 3.0e38f;
-	int best_id = -2;
-	const bool is_active = inb;
-	bool walking = false;
-	if (is_active) {
-		float tenter = 0.0f, texit = 3.0e38f;
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			o[k] = rays[p * 6 + k];
-			d[k] = rays[p * 6 + 3 + k];
-		}
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			float lo = g.lo[k], hi = g.lo[k] + g.cs[k] * (float)g.dims[k];
-			if (d[k] != 0.0f) {
-				float inv = 1.0f / d[k];
-				float t0 = (lo - o[k]) * inv, t1 = (hi - o[k]) * inv;
-				if (t0 > t1) {
-					float s = t0;
-					t0 = t1;
-					t1 = s;
-				}
-				if (t0 > tenter)
-					tenter = t0;
-				if (t1 < texit)
-					texit = t1;
-			} else if (o[k] < lo || o[k] > hi) {
-				texit = -1.0f;
-			}
-		}
-		if (tenter <= texit) {
-			walking = true;
-#pragma unroll
-			for (int k = 0; k < 3; k++) {
-				float pe = o[k] + tenter * d[k];
-				c[k] = d_dcell(g, k, pe);
-				if (d[k] > 0.0f) {
-					step[k] = 1;
-					tmax[k] = ((g.lo[k] + (float)(c[k] + 1) * g.cs[k]) - o[k]) / d[k];
-					tdelta[k] = g.cs[k] / d[k];
-				} else if (d[k] < 0.0f) {
-					step[k] = -1;
-					tmax[k] = ((g.lo[k] + (float)c[k] * g.cs[k]) - o[k]) / d[k];
-					tdelta[k] = -g.cs[k] / d[k];
-				} else {
-					step[k] = 0;
-					tmax[k] = 3.0e38f;
-					tdelta[k] = 3.0e38f;
-				}
-			}
-		}
-	}
-	// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
-	int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3;
-	while (__ballot(walking) != 0ull) {
-		// The walk itself does not depend on what the cells hold, so the next DDA_AHEAD cells are
-		// planned first and their headers fetched together: one memory round trip per DDA_AHEAD steps.
-		u32 pcell[DDA_AHEAD], psp[DDA_AHEAD], poff[DDA_AHEAD];
-		float ptnext[DDA_AHEAD];
-		bool pvalid[DDA_AHEAD], pend[DDA_AHEAD];
-		bool planning = walking;
-#pragma unroll
-		for (int q = 0; q < DDA_AHEAD; q++) {
-			pvalid[q] = planning;
-			pend[q] = false;
-			pcell[q] = 0;
-			ptnext[q] = 0.0f;
-			if (planning) {
-				pcell[q] = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
-				int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
-				ptnext[q] = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
-				// step along ax (written out: no dynamically indexed registers)
-				bool outside;
-				if (ax == 0) {
-					c[0] += step[0];
-					outside = step[0] == 0 || c[0] < 0 || c[0] >= g.dims[0];
-					tmax[0] += tdelta[0];
-				} else if (ax == 1) {
-					c[1] += step[1];
-					outside = step[1] == 0 || c[1] < 0 || c[1] >= g.dims[1];
-					tmax[1] += tdelta[1];
-				} else {
-					c[2] += step[2];
-					outside = step[2] == 0 || c[2] < 0 || c[2] >= g.dims[2];
-					tmax[2] += tdelta[2];
-				}
-				if (outside || --guard <= 0) {
-					pend[q] = true; // the walk ends after this cell unless it ends there with a hit
-					planning = false;
-				}
-			}
-		}
-#pragma unroll
-		for (int q = 0; q < DDA_AHEAD; q++) {
-			psp[q] = pvalid[q] ? span[pcell[q]] : 0u;
-			poff[q] = pvalid[q] ? offset[pcell[q]] : 0u;
-		}
-#pragma unroll
-		for (int q = 0; q < DDA_AHEAD; q++) {
-			const bool here = walking && pvalid[q];
-			const u32 sp = here ? psp[q] : 0u, off = poff[q];
-			if (COUNT && here) {
-				n_cells++;
-				n_tests += sp;
-			}
-			// small lists: the owning lane tests them itself, in list order
-			if (here && sp < DDA_COOP) {
-				for (u32 r = 0; r < sp; r++) {
-					u32 f = value_list[off + r];
-					float t9[9], t;
-					d_load_triangle<REC>(rec, verts, tris, f, o[0], o[1], o[2], t9);
-					if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
-						best_t = t;
-						best_id = (int)f;
-					}
-				}
-			}
-			// long lists: one owner at a time, 64 triangles per round
-			unsigned long long heavy = __ballot(here && sp >= DDA_COOP);
-			while (heavy != 0ull) {
-				const int l = (int)__builtin_ctzll(heavy);
-				heavy &= heavy - 1ull;
-				const float ox = __shfl(o[0], l), oy = __shfl(o[1], l), oz = __shfl(o[2], l);
-				const float dl[3] = { __shfl(d[0], l), __shfl(d[1], l), __shfl(d[2], l) };
-				const float bt = __shfl(best_t, l);
-				const u32 spl = (u32)__shfl((int)sp, l), offl = (u32)__shfl((int)off, l);
-				unsigned long long kbest = ~0ull;
-				for (u32 base = 0; base < spl; base += 64) {
-					const u32 r = base + (u32)lane;
-					unsigned long long key = ~0ull;
-					if (r < spl) {
-						float t9[9], t;
-						d_load_triangle<REC>(rec, verts, tris, value_list[offl + r], ox, oy, oz, t9);
-						if (d_mt_core(&t9[0], &t9[3], &t9[6], dl, &t) && t > 0.0f && t < bt)
-							key = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)r;
-					}
-					key = d_wave_min_u64(key);
-					kbest = key < kbest ? key : kbest;
-				}
-				if (lane == l && kbest != ~0ull) {
-					best_t = __uint_as_float((u32)(kbest >> 32));
-					best_id = (int)value_list[off + (u32)(kbest & 0xFFFFFFFFull)];
-				}
-			}
-			if (here) {
-				if (best_id >= 0 && best_t <= ptnext[q]) {
-					res_t = best_t;
-					res_id = best_id;
-					walking = false;
-				} else if (pend[q]) {
-					walking = false;
-				}
-			}
-		}
-	}
-	if (inb) {
-		hit_t[p] = res_t;
-		hit_id[p] = res_id;
-	}
-	if (COUNT && inb) {
-		// work counters of the algorithmic-byte formula: candidates tested, cells visited, active rays
-		if (n_tests)
-			atomicAdd(&counters[0], (unsigned long long)n_tests);
-		if (n_cells)
-			atomicAdd(&counters[1], (unsigned long long)n_cells);
-		atomicAdd(&counters[2], 1ull);
-	}
-	} // groups
-}
-
-extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
-			      const unsigned *d_offset, const float *d_vertlist, const int *d_trilist,
-			      const float *d_rays, const int *d_active, float *d_hit_t, int *d_hit_id)
-{
-	if (!ctx || !d_value_list || !d_span || !d_offset || !d_vertlist || !d_trilist || !d_rays || !d_active ||
-	    !d_hit_t || !d_hit_id)
-		return ugrt_fail(UGRT_EINVAL, "trace_dda: null argument");
-	Grid &G = ctx->grid[UGRT_GRID_UNIFORM];
-	if (!G.valid)
-		return ugrt_fail(UGRT_EINVAL, "trace_dda: build the uniform grid first (it defines the cell geometry)");
-	UGRT_HIP(hipSetDevice(ctx->device));
-	DGrid g;
-	for (int k = 0; k < 3; k++) {
-		g.lo[k] = G.ug[k];
-		g.cs[k] = G.ug[3 + k];
-		g.inv[k] = G.ug[6 + k];
-		g.dims[k] = G.dims[k];
-	}
-	int rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)ctx->npix * 4)))
-		return rc;
-	u32 *list = (u32 *)ctx->wscan.p, *dcount = ctx->d_small + 2;
-	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
-	const float4 *rec = use_rec ? (const float4 *)ctx->trirec.p : (const float4 *)nullptr;
-	const bool counting = (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) != 0;
-	unsigned long long *dc = (unsigned long long *)(ctx->d_small + 8);
-	if (!counting)
-		ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
-	UGRT_HIP(hipMemsetAsync(dcount, 0, 4, ctx->stream));
-	hipLaunchKernelGGL(k_dda_prepare, dim3((ctx->npix + 4 * DDA_PREP_SPAN - 1) / (4 * DDA_PREP_SPAN)), dim3(256), 0, ctx->stream, d_active, ctx->p0,
-			   ctx->npix, d_hit_t, d_hit_id, list, dcount);
-	if (!counting) {
-		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
-		ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
-	}
-	UGRT_HIP(hipGetLastError());
-	// rays per wave / list length from which the whole wave tests a cell (tunable for experiments)
-	u32 DDA_RPW = ctx->opt_dda_rpw > 0 ? (u32)ctx->opt_dda_rpw : 32u, DDA_COOP = 8u;
-	if (const char *e = getenv("UGRT_DDA_RPW"))
-		DDA_RPW = (u32)atoi(e);
-	if (const char *e = getenv("UGRT_DDA_COOP"))
-		DDA_COOP = (u32)atoi(e);
-	if (DDA_RPW < 1u || DDA_RPW > 64u)
-		DDA_RPW = 32u;
-	if (DDA_COOP < 1u)
-		DDA_COOP = 1u;
-	const int blocks = launch_blocks_for((u32)ctx->npix / DDA_RPW + 1u);
-#define UGRT_LAUNCH_DDA(CNTV, RECV, DC)                                                                              \
-	hipLaunchKernelGGL((k_trace_dda<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
-			   d_offset, d_vertlist, d_trilist, rec, d_rays, (const u32 *)list, (const u32 *)dcount,     \
-			   d_hit_t, d_hit_id, DC, DDA_RPW, DDA_COOP)
-	if (counting) {
-		// counting variant (never the timed one): same traversal + three atomics per ray
-		UGRT_HIP(hipMemsetAsync(dc, 0, 3 * sizeof(unsigned long long), ctx->stream));
-		if (use_rec)
-			UGRT_LAUNCH_DDA(true, true, dc);
-		else
-			UGRT_LAUNCH_DDA(true, false, dc);
-		UGRT_HIP(hipGetLastError());
-		unsigned long long h[3];
-		UGRT_HIP(hipMemcpyAsync(h, dc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-		UGRT_HIP(hipStreamSynchronize(ctx->stream));
-		ctx->stats[3] = h[0];
-		ctx->stats[4] = h[1];
-		ctx->stats[5] = h[2];
-		return UGRT_OK;
-	}
-	if (use_rec)
-		UGRT_LAUNCH_DDA(false, true, (unsigned long long *)nullptr);
-	else
-		UGRT_LAUNCH_DDA(false, false, (unsigned long long *)nullptr);
-#undef UGRT_LAUNCH_DDA
-	ugrt_prof_end(ctx, UGRT_ST_TRACE_DDA);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;
 }

@@ -227,3 +227,19 @@ class Context:
         a = (C.c_ulonglong * 8)()
         check(lib.ugrt_stats_get(self._h, a))
         return list(a)
+
+    DDA_STATS = ("wave_iterations", "cell_groups", "group_rays", "cull_batches", "cull_tests", "exact_rounds",
+                 "exact_round_rays", "lone_ray_tests")
+
+    def stats_dda(self):
+        """Work sharing of the beam kernel's last counting launch (a FLAG_COUNT_WORK context)."""
+        a = (C.c_ulonglong * 46)()
+        check(lib.ugrt_stats_dda(self._h, a, 46))
+        d = dict(zip(self.DDA_STATS, list(a)[:8]))
+        d["waves_by_log2_cycles_over_4096"] = list(a)[8:24]
+        d["cycles_sum"], d["cycles_max"] = a[24], a[25]
+        d["phase_cycles"] = dict(zip(("plan_headers", "job_list", "operand_arrival", "box", "cull", "exact_rounds",
+                                      "lone_rays", "rest"), list(a)[26:34]))
+        d["heavy_waves"] = dict(zip(("plan_headers", "job_list", "operand_arrival", "box", "cull", "exact_rounds",
+                                     "lone_rays", "rest", "waves", "rounds", "groups", "iterations"), list(a)[34:46]))
+        return d

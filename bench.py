@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: every stage after the other (default: light/uniform grid builds and the bounce "
                          "on a second stream beside the camera and shadow passes)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="launch-shape option for every context (ugrt_ctx_set_option), e.g. dda_kernel=1")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
@@ -191,6 +193,10 @@ def main():
     ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
     r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
                       overlap=not args.no_overlap)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        for c in [ctx] + ([r.aux] if r.aux is not None else []):
+            c.set_option(k, int(v))
     gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world, host_staging=rehearse)
 
     reflect = not args.no_reflect

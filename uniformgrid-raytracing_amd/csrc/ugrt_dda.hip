@@ -314,14 +314,14 @@ __global__ __launch_bounds__(64) void k_trace_dda_ray(DGrid g, const u32 *__rest
 // the bundle is represented by the point o' = o + t_in * d where it enters the current cell: the points of
 // a bundle then lie within a fraction of a cell of each other.  With the boxes o' in oc +- orad, d in
 // dc +- dr:
-//     A = d.(e2 x (oc - v0)) + d.(e2 x (o' - oc)),   |second term| <= |d| |e2| |o' - oc| =: sqrt(3) c R
-// and likewise for B (e1) and A + B - det (e2 - e1); the first terms are the interval dot products of the
-// single-origin cull (d_cull_cr).  The margins cover the rounding of the exact test, whose operands are
+//     A = d.(e2 x (oc - v0)) + (o' - oc).(d x e2),   |second term| <= sum_k orad_k max|(d x e2)_k|
+// and likewise for B (e1 x d) and A + B - det (d x (e2 - e1)), the maxima taken over the direction box; the
+// first terms are the interval dot products of the single-origin cull (d_cull_cr).  (Bounding the second term
+// by |d| |e2| |o' - oc| instead leaves twice as many triangles for the exact tests.)  The margins cover the rounding of the exact test, whose operands are
 // tvec = o - v0 with the ray's own origin: `reach` bounds |o - oc|.  A culled triangle fails the exact
 // float test on every ray of the bundle, so results do not change by a bit.
 struct BeamBox {
-	float oc[3], dc[3], dr[3];
-	float R;     // >= |d|_2 * |o' - oc|_2 over the bundle
+	float oc[3], orad[3], dc[3], dr[3];
 	float reach; // >= |o - oc|_inf over the bundle
 };
 
@@ -341,8 +341,8 @@ __device__ __forceinline__ BeamBox d_beam_box(const float *o, const float *d, fl
 		float lo = d_wave_fmin(in ? p : inf), hi = d_wave_fmax(in ? p : -inf);
 		bx.oc[k] = 0.5f * (lo + hi);
 		// half width + the distance of the computed o' from the exact point of the ray (a few ulps of |o'|)
-		const float orad = 0.5f * (hi - lo) * 1.0001f + 7.63e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f;
-		on2 += orad * orad;
+		bx.orad[k] = 0.5f * (hi - lo) * 1.0001f + 7.63e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f;
+		on2 += bx.orad[k] * bx.orad[k];
 		lo = d_wave_fmin(in ? d[k] : inf);
 		hi = d_wave_fmax(in ? d[k] : -inf);
 		bx.dc[k] = 0.5f * (lo + hi);
@@ -352,7 +352,6 @@ __device__ __forceinline__ BeamBox d_beam_box(const float *o, const float *d, fl
 	}
 	const float tmax = d_wave_fmax(in ? tin : 0.0f);
 	const float on = __builtin_sqrtf(on2) * 1.0001f, dmax = __builtin_sqrtf(dm2) * 1.0001f;
-	bx.R = dmax * on * 1.0001f;
 	bx.reach = (tmax * dmax + on) * 1.001f;
 	// uniform values: keep them in scalar registers
 #pragma unroll
@@ -360,8 +359,8 @@ __device__ __forceinline__ BeamBox d_beam_box(const float *o, const float *d, fl
 		bx.oc[k] = d_uniform(bx.oc[k]);
 		bx.dc[k] = d_uniform(bx.dc[k]);
 		bx.dr[k] = d_uniform(bx.dr[k]);
+		bx.orad[k] = d_uniform(bx.orad[k]);
 	}
-	bx.R = d_uniform(bx.R);
 	bx.reach = d_uniform(bx.reach);
 	return bx;
 }
@@ -387,13 +386,19 @@ __device__ __forceinline__ bool d_cull_beam(const float *v0, const float *e1, co
 	const float Dr = fabsf(nD[0]) * bx.dr[0] + fabsf(nD[1]) * bx.dr[1] + fabsf(nD[2]) * bx.dr[2];
 	if (!(Dm + Dr < 1e15f && Dm - Dr > -1e15f))
 		return false;
-	const float s3 = 1.7321f * bx.R;
+	// |w . (d x e)| over the boxes of w = o' - oc and d: sum_k orad_k * (|(dc x e)_k| + the spread of d)
+#define D_ORIGIN_TERM(E)                                                                                        \
+	(bx.orad[0] * (fabsf(bx.dc[1] * E[2] - bx.dc[2] * E[1]) + bx.dr[1] * fabsf(E[2]) + bx.dr[2] * fabsf(E[1])) + \
+	 bx.orad[1] * (fabsf(bx.dc[2] * E[0] - bx.dc[0] * E[2]) + bx.dr[2] * fabsf(E[0]) + bx.dr[0] * fabsf(E[2])) + \
+	 bx.orad[2] * (fabsf(bx.dc[0] * E[1] - bx.dc[1] * E[0]) + bx.dr[0] * fabsf(E[1]) + bx.dr[1] * fabsf(E[0])))
+	const float e21[3] = { e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2] };
 	const float Am = nA[0] * bx.dc[0] + nA[1] * bx.dc[1] + nA[2] * bx.dc[2];
-	const float Ar = fabsf(nA[0]) * bx.dr[0] + fabsf(nA[1]) * bx.dr[1] + fabsf(nA[2]) * bx.dr[2] + s3 * c;
+	const float Ar = (fabsf(nA[0]) * bx.dr[0] + fabsf(nA[1]) * bx.dr[1] + fabsf(nA[2]) * bx.dr[2] + D_ORIGIN_TERM(e2)) * 1.0001f;
 	const float Bm = nB[0] * bx.dc[0] + nB[1] * bx.dc[1] + nB[2] * bx.dc[2];
-	const float Br = fabsf(nB[0]) * bx.dr[0] + fabsf(nB[1]) * bx.dr[1] + fabsf(nB[2]) * bx.dr[2] + s3 * b;
+	const float Br = (fabsf(nB[0]) * bx.dr[0] + fabsf(nB[1]) * bx.dr[1] + fabsf(nB[2]) * bx.dr[2] + D_ORIGIN_TERM(e1)) * 1.0001f;
 	const float Cm = nC[0] * bx.dc[0] + nC[1] * bx.dc[1] + nC[2] * bx.dc[2];
-	const float Cr = fabsf(nC[0]) * bx.dr[0] + fabsf(nC[1]) * bx.dr[1] + fabsf(nC[2]) * bx.dr[2] + s3 * (b + c);
+	const float Cr = (fabsf(nC[0]) * bx.dr[0] + fabsf(nC[1]) * bx.dr[1] + fabsf(nC[2]) * bx.dr[2] + D_ORIGIN_TERM(e21)) * 1.0001f;
+#undef D_ORIGIN_TERM
 	const float mC = mA + mB + mD;
 	if (Dm - Dr > mD) // det > 0 for every ray of the bundle
 		return (Am + Ar < -mA) || (Bm + Br < -mB) || (Cm - Cr > mC);
@@ -448,7 +453,7 @@ enum { DS_ITER = 3, DS_GROUPS, DS_GROUP_LANES, DS_CULL_BATCHES, DS_CULL_TESTS, D
 	} while (0)
 
 template <bool COUNT, bool REC>
-__global__ __launch_bounds__(64, 4) void k_trace_dda_beam(DGrid g, const u32 *__restrict__ value_list,
+__global__ __launch_bounds__(64, 3) void k_trace_dda_beam(DGrid g, const u32 *__restrict__ value_list,
 							const u32 *__restrict__ span, const u32 *__restrict__ offset,
 							const float *__restrict__ verts, const int *__restrict__ tris,
 							const float4 *__restrict__ rec, const float *__restrict__ rays,

@@ -265,9 +265,17 @@ __device__ __forceinline__ T d_wave_reduce(T v, T identity)
 	d_from_int(__builtin_amdgcn_readlane(d_as_int(v), 63), &r);
 	return r;
 }
-__device__ __forceinline__ float d_wave_fmin(float v) { return d_wave_reduce<DOpMin>(v, __builtin_huge_valf()); }
-__device__ __forceinline__ float d_wave_fmax(float v) { return d_wave_reduce<DOpMax>(v, -__builtin_huge_valf()); }
 __device__ __forceinline__ int d_wave_imin(int v) { return d_wave_reduce<DOpMin>(v, 0x7FFFFFFF); }
 __device__ __forceinline__ int d_wave_imax(int v) { return d_wave_reduce<DOpMax>(v, (int)0x80000000); }
+// floats go through their order-preserving integer image: integer min/max fold into the DPP instruction
+// (v_min_i32_dpp: one instruction per step), the float forms need a move and a canonicalisation beside it
+__device__ __forceinline__ int d_ordered(float f)
+{
+	const int b = __float_as_int(f);
+	return b ^ ((b >> 31) & 0x7FFFFFFF);
+}
+__device__ __forceinline__ float d_unordered(int b) { return __int_as_float(b ^ ((b >> 31) & 0x7FFFFFFF)); }
+__device__ __forceinline__ float d_wave_fmin(float v) { return d_unordered(d_wave_imin(d_ordered(v))); }
+__device__ __forceinline__ float d_wave_fmax(float v) { return d_unordered(d_wave_imax(d_ordered(v))); }
 
 #endif

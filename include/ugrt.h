@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define UGRT_VERSION 100
+#define UGRT_VERSION 101
 
 enum {
 	UGRT_OK = 0,
@@ -93,7 +93,7 @@ typedef struct ugrt_scene ugrt_scene; /* host scene = class Model, scene.h:13-57
 typedef struct ugrt_config {
 	int width, height;       /* SCREEN_WIDTH, SCREEN_HEIGHT; multiples of tile */
 	int tile;                /* NUM_THREADS_X = NUM_THREADS_Y; must be 8 */
-	int slabs;               /* NUM_SLABS; must be 1 (main.cu.h:18) */
+	int slabs;               /* NUM_SLABS (main.cu.h:18), 1..64: z-slabs of the perspective and the light grid */
 	int light_nbx, light_nby; /* spherical light grid, 128 x 128 in the reference; even */
 	int row_begin, row_end;  /* tile rows [begin,end) this context renders (multi-GPU band);
 				    0, height/tile for the whole image */
@@ -124,6 +124,14 @@ typedef struct ugrt_grid_info {
 	unsigned cells_used;             /* "Number of actual cells", frustum_grid.h:337; final once the
 					    stream has been synchronised after the build */
 } ugrt_grid_info;
+
+/* the z-slab stage of FrustumGrid::buildGrid / buildSphericalGrid (NUM_SLABS > 1) */
+typedef struct ugrt_slab_info {
+	int slabs;
+	float *d_proj_coord_z; /* [num_faces] d_projCoordZ: min ndc z (perspective) / min distance from the light
+				  (spherical) per triangle, grid_kernel.cu:212,651; NULL when slabs == 1 */
+	float z_min, z_max;    /* the host loop's zMin / zMax, frustum_grid.h:221-241 / :384-404 */
+} ugrt_slab_info;
 
 /* ---- library ---------------------------------------------------------- */
 int ugrt_version(void);
@@ -200,6 +208,9 @@ int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, const float 
 int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int num_faces,
 			    const float bbmin[3], const float bbmax[3]);
 int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out);
+/* With slabs > 1 the arrays of ugrt_grid_info hold num_cells = cells * slabs entries, cell-major
+ * (key = cell * slabs + slab, grid_kernel.cu:322).  This call synchronises the stream. */
+int ugrt_grid_get_slabs(ugrt_ctx *ctx, int which, ugrt_slab_info *out);
 /* with UGRT_FLAG_STATIC_GEOMETRY: the vertex or face array was rewritten by the caller */
 int ugrt_geometry_changed(ugrt_ctx *ctx);
 /* cudppSort(plan, keys, values, bits, n) with CUDPP_SORT_RADIX on (uint key, uint value) pairs

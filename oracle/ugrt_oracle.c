@@ -519,6 +519,66 @@ void orc_fill_2d(const int *rng, const u32 *scanList, int F, int nby, u32 *keyLi
 	}
 }
 
+/*
+ * Host z-range loop of buildGrid (frustum_grid.h:221-241: zMin = +2, zMax = -2) and of
+ * buildSphericalGrid (:384-404: 9999.9 / -9999.9): zMin = smallest non-negative value, zMax = largest.
+ */
+void orc_zrange(const float *projCoordZ, int F, float zmin_init, float zmax_init, float *zMin_out, float *zMax_out)
+{
+	float zMin = zmin_init, zMax = zmax_init;
+	int i;
+	for (i = 0; i < F; i++) {
+		if (zMin > projCoordZ[i] && projCoordZ[i] >= 0.0f)
+			zMin = projCoordZ[i];
+		if (zMax < projCoordZ[i])
+			zMax = projCoordZ[i];
+	}
+	*zMin_out = zMin;
+	*zMax_out = zMax;
+}
+
+/*
+ * SlabKernel (grid_kernel.cu:334-352).  The reference leaves zList[f] untouched for a negative
+ * depth (uninitialised memory); here such a triangle keeps the caller's value, which
+ * the build defines as 0.
+ */
+void orc_slab_kernel(const float *projCoordZ, int F, int slabs, float zMin, float zMax, u32 *zList)
+{
+	int curface;
+	for (curface = 0; curface < F; curface++) {
+		float pCoord = projCoordZ[curface];
+		if (pCoord >= 0.0f) {
+			unsigned binID = ugrt_f2u((float)slabs * (float)((pCoord - zMin) / (zMax - zMin)));
+			if (binID >= (unsigned)slabs)
+				binID = (unsigned)slabs - 1u;
+			zList[curface] = binID;
+		}
+	}
+}
+
+/* DSFillkernel / DS_spherical_Fillkernel with NUM_SLABS > 1 (grid_kernel.cu:310,322 / :819,846):
+ * key = ((gx*nby + gy)*slabs + clamp(zSlabs[f])). */
+void orc_fill_slabs(const int *rng, const u32 *scanList, const u32 *zList, int F, int nby, int slabs, u32 *keyList,
+		    u32 *valueList)
+{
+	int curface;
+#pragma omp parallel for schedule(dynamic, 1024)
+	for (curface = 0; curface < F; curface++) {
+		u32 offset = curface ? scanList[curface - 1] : 0;
+		int gxmin = rng[curface * 4 + 0], gxmax = rng[curface * 4 + 1];
+		int gymin = rng[curface * 4 + 2], gymax = rng[curface * 4 + 3];
+		int size_x = gxmax - gxmin + 1, size_y = gymax - gymin + 1, i, j;
+		int gzmin = orc_clampi((int)zList[curface], 0, slabs - 1);
+		if (scanList[curface] == offset)
+			continue;
+		for (i = 0; i < size_x; i++)
+			for (j = 0; j < size_y; j++) {
+				keyList[offset + i * size_y + j] = (u32)(((gxmin + i) * nby + (gymin + j)) * slabs + gzmin);
+				valueList[offset + i * size_y + j] = (u32)curface;
+			}
+	}
+}
+
 /* cudppSort key-value radix (frustum_grid.h:298, decision_data.h:177):
  * any STABLE sort by key is the same function; counting sort on keys < nkeys. */
 int orc_stable_sort_pairs(u32 *keys, u32 *values, u32 n, u32 nkeys)
@@ -770,6 +830,131 @@ void orc_trace_primary(const float *cc, const float *tex, int W, int H, int nbx,
 	}
 }
 
+/*
+ * rckernel_alpha with NUM_SLABS = slabs > 1 (trace_kernel.cu:84-270).  Per tile the slabs are walked front
+ * to back; a hit is accepted (rayDone = 2) in the slab whose index equals floor(ndc_z * slabs) (isWithin,
+ * :56-82); the tile stops when all 64 rays are accepted (:217-228).  Reproduced as written, including:
+ *  - isWithin returns 0 for a ray that IS accepted (:59-62), so when the tile goes on (another ray is still
+ *    open) the accepted ray falls back to "no hit" while keeping oldt, and ends as a miss unless a nearer
+ *    triangle of a later slab is accepted;
+ *  - triangles are binned by their slab relative to [zMin, zMax] (SlabKernel), hits are gated by the
+ *    absolute ndc depth.
+ */
+void orc_trace_primary_slabs(const float *cc, const float *tex, int W, int H, int nbx, int nby, int gy_lo,
+			     int gy_hi, int slabs, const u32 *value_list, const u32 *span, const u32 *offset,
+			     const float *vertlist, const int *trilist, float *normal_out, float *t_out,
+			     float *dir_out, int *shadowed_out, int *id_out)
+{
+	int tile;
+	int ntiles = nbx * (gy_hi - gy_lo);
+#pragma omp parallel for schedule(dynamic, 1)
+	for (tile = 0; tile < ntiles; tile++) {
+		int bx = tile / (gy_hi - gy_lo);
+		int by = gy_lo + tile % (gy_hi - gy_lo);
+		int cell = bx * nby + by;
+		float ray_direction[64][3], e1[64][3], e2[64][3], oldt[64];
+		int rayDone[64], lane, slab, beam_done = 0;
+		u32 tri_intersected[64];
+		for (lane = 0; lane < 64; lane++) {
+			orc_ray_dir(cc, tex, bx * 8 + (lane & 7), by * 8 + (lane >> 3), W, H, ray_direction[lane]);
+			oldt[lane] = 99999999.9f;
+			rayDone[lane] = 0;
+			tri_intersected[lane] = 0;
+			e1[lane][0] = e1[lane][1] = e1[lane][2] = 0;
+			e2[lane][0] = e2[lane][1] = e2[lane][2] = 0;
+		}
+		for (slab = 0; slab < slabs && !beam_done; slab++) {
+			u32 sp = span[cell * slabs + slab], off = offset[cell * slabs + slab], r;
+			int all_done = 1;
+			for (lane = 0; lane < 64; lane++) {
+				if (rayDone[lane] != 2) {
+					for (r = 0; r < sp; r++) {
+						u32 curface = value_list[off + r];
+						int face1 = 3 * trilist[curface * 3 + 0];
+						int face2 = 3 * trilist[curface * 3 + 1];
+						int face3 = 3 * trilist[curface * 3 + 2];
+						float vd[9], value;
+						vd[0] = vertlist[face1 + 0];
+						vd[1] = vertlist[face1 + 1];
+						vd[2] = vertlist[face1 + 2];
+						vd[3] = vertlist[face2 + 0] - vd[0];
+						vd[4] = vertlist[face2 + 1] - vd[1];
+						vd[5] = vertlist[face2 + 2] - vd[2];
+						vd[6] = vertlist[face3 + 0] - vd[0];
+						vd[7] = vertlist[face3 + 1] - vd[1];
+						vd[8] = vertlist[face3 + 2] - vd[2];
+						vd[0] = cc[0] - vd[0];
+						vd[1] = cc[1] - vd[1];
+						vd[2] = cc[2] - vd[2];
+						value = orc_intersect_tri_uv(&vd[0], &vd[3], &vd[6], ray_direction[lane], oldt[lane]);
+						if (value) {
+							oldt[lane] = value;
+							rayDone[lane] = 1;
+							tri_intersected[lane] = off + r;
+							e1[lane][0] = vd[3];
+							e1[lane][1] = vd[4];
+							e1[lane][2] = vd[5];
+							e2[lane][0] = vd[6];
+							e2[lane][1] = vd[7];
+							e2[lane][2] = vd[8];
+						}
+					}
+				}
+				/* isWithin, trace_kernel.cu:56-82 */
+				if (rayDone[lane] == 0 || rayDone[lane] == 2) {
+					rayDone[lane] = 0;
+				} else {
+					float point[4], tmp[4];
+					int z_value;
+					point[0] = cc[0] + oldt[lane] * ray_direction[lane][0];
+					point[1] = cc[1] + oldt[lane] * ray_direction[lane][1];
+					point[2] = cc[2] + oldt[lane] * ray_direction[lane][2];
+					point[3] = 1.0f;
+					orc_mulmv(tmp, &cc[48], point);
+					tmp[2] /= tmp[3];
+					z_value = ugrt_floor2i(tmp[2] * (float)slabs);
+					rayDone[lane] = (z_value == slab) ? 2 : 1;
+				}
+				if (rayDone[lane] != 2)
+					all_done = 0;
+			}
+			beam_done = all_done;
+		}
+		for (lane = 0; lane < 64; lane++) {
+			int pixelID = (by * 8 + (lane >> 3)) * W + bx * 8 + (lane & 7);
+			if (rayDone[lane] == 2) {
+				float nrm[3];
+				NORMALIZE(e1[lane]);
+				NORMALIZE(e2[lane]);
+				CROSS(nrm, e1[lane], e2[lane]);
+				NORMALIZE(nrm);
+				if (nrm[0] < 0)
+					nrm[0] *= -1;
+				if (nrm[1] < 0)
+					nrm[1] *= -1;
+				if (nrm[2] < 0)
+					nrm[2] *= -1;
+				t_out[pixelID] = oldt[lane];
+				shadowed_out[pixelID] = 0;
+				id_out[pixelID] = (int)value_list[tri_intersected[lane]];
+				normal_out[pixelID * 3 + 0] = nrm[0];
+				normal_out[pixelID * 3 + 1] = nrm[1];
+				normal_out[pixelID * 3 + 2] = nrm[2];
+			} else {
+				t_out[pixelID] = -1.0f;
+				shadowed_out[pixelID] = 0;
+				id_out[pixelID] = -2;
+				normal_out[pixelID * 3 + 0] = -1.0f;
+				normal_out[pixelID * 3 + 1] = -1.0f;
+				normal_out[pixelID * 3 + 2] = -1.0f;
+			}
+			dir_out[pixelID * 3 + 0] = ray_direction[lane][0];
+			dir_out[pixelID * 3 + 1] = ray_direction[lane][1];
+			dir_out[pixelID * 3 + 2] = ray_direction[lane][2];
+		}
+	}
+}
+
 /* ------------------------------------------------------------------------- */
 /* Shadow rays: mapping, re-ordering, trace                                   */
 /* ------------------------------------------------------------------------- */
@@ -882,11 +1067,30 @@ static int orc_is_smaller(const float *a, const float *b, const float *ref)
  * strict == 0 traces every chunk.  The sentinel cell (>= C) has span 0 (Q11).
  * is_shadowed is only ever set to 1.  counters: [0] MT tests, [1] refs staged.
  */
+void orc_trace_shadow_slabs(const float *cc, const u32 *curflist, const float *vertlist, const int *trilist,
+			    const u32 *blockcnt, const u32 *blockcntscan, u32 C, int slabs, const float *t_value_list,
+			    const float *ray_direction_list, int *is_shadowed, const u32 *d_map,
+			    const u32 *prefixmap, const float *cmPt, u32 nchunks, u32 launch_blocks, int n,
+			    int strict, unsigned long long *counters);
+
 void orc_trace_shadow(const float *cc, const u32 *curflist, const float *vertlist, const int *trilist,
 		      const u32 *blockcnt, const u32 *blockcntscan, u32 C, const float *t_value_list,
 		      const float *ray_direction_list, int *is_shadowed, const u32 *d_map,
 		      const u32 *prefixmap, const float *cmPt, u32 nchunks, u32 launch_blocks, int n,
 		      int strict, unsigned long long *counters)
+{
+	orc_trace_shadow_slabs(cc, curflist, vertlist, trilist, blockcnt, blockcntscan, C, 1, t_value_list,
+			       ray_direction_list, is_shadowed, d_map, prefixmap, cmPt, nchunks, launch_blocks, n, strict,
+			       counters);
+}
+
+/* NUM_SLABS = slabs: the block walks the lists of all slabs of its light cell (light_kernel.cu:105-113,
+ * blockcnt[cell*NUM_SLABS + p]); a ray is shadowed as soon as any of them holds an occluder. */
+void orc_trace_shadow_slabs(const float *cc, const u32 *curflist, const float *vertlist, const int *trilist,
+			    const u32 *blockcnt, const u32 *blockcntscan, u32 C, int slabs, const float *t_value_list,
+			    const float *ray_direction_list, int *is_shadowed, const u32 *d_map,
+			    const u32 *prefixmap, const float *cmPt, u32 nchunks, u32 launch_blocks, int n,
+			    int strict, unsigned long long *counters)
 {
 	long long k, kend;
 	unsigned long long tests = 0, refs = 0;
@@ -901,14 +1105,18 @@ void orc_trace_shadow(const float *cc, const u32 *curflist, const float *vertlis
 		u32 start = prefixmap[k];
 		u32 end = (k + 1 < (long long)nchunks) ? prefixmap[k + 1] : (u32)n;
 		u32 cell = d_map[n + start];
-		u32 sp = (cell < C) ? blockcnt[cell] : 0;
-		u32 off = (cell < C) ? blockcntscan[cell] : 0;
 		u32 q, r;
+		int p;
+		for (p = 0; p < slabs; p++) {
+		u32 sp = (cell < C) ? blockcnt[cell * (u32)slabs + (u32)p] : 0;
+		u32 off = (cell < C) ? blockcntscan[cell * (u32)slabs + (u32)p] : 0;
 		refs += sp;
 		for (q = start; q < end; q++) {
 			int pseudoPixelId = (int)d_map[q];
 			float rayDirection[3], ptIntersection[3];
 			float tVal = t_value_list[pseudoPixelId];
+			if (is_shadowed[pseudoPixelId] == 1 && p > 0)
+				continue; /* rayDoneMap == 2 from an earlier slab */
 			rayDirection[0] = cmPt[0] + tVal * ray_direction_list[pseudoPixelId * 3 + 0];
 			rayDirection[1] = cmPt[1] + tVal * ray_direction_list[pseudoPixelId * 3 + 1];
 			rayDirection[2] = cmPt[2] + tVal * ray_direction_list[pseudoPixelId * 3 + 2];
@@ -951,6 +1159,7 @@ void orc_trace_shadow(const float *cc, const u32 *curflist, const float *vertlis
 				}
 			}
 		}
+		} /* slabs */
 	}
 	if (counters) {
 		counters[0] = tests;

@@ -92,7 +92,18 @@ def _finish_grid(rng_fill, sizes, F, C_cells, nkeys):
                 scan=scan)
 
 
-def grid_perspective(cc, faces, verts, nbx, nby, rows=None):
+def _slab_fill(rng, zmin, F, nby, slabs, zinit):
+    """zMin/zMax host loop + SlabKernel + the fill with slab keys (NUM_SLABS > 1)."""
+    zlo, zhi = C.c_float(), C.c_float()
+    _lib.orc_zrange(_p(zmin), C.c_int(F), C.c_float(zinit[0]), C.c_float(zinit[1]), C.byref(zlo), C.byref(zhi))
+    zlist = np.zeros(F, np.uint32)
+    _lib.orc_slab_kernel(_p(zmin), C.c_int(F), C.c_int(slabs), zlo, zhi, _p(zlist))
+    fill = lambda scan, k, v: _lib.orc_fill_slabs(_p(rng), _p(scan), _p(zlist), C.c_int(F), C.c_int(nby),
+                                                  C.c_int(slabs), _p(k), _p(v))
+    return fill, zlist, (zlo.value, zhi.value)
+
+
+def grid_perspective(cc, faces, verts, nbx, nby, rows=None, slabs=1):
     """FrustumGrid::buildGrid, frustum_grid.h:210-366."""
     faces, verts = _i32(faces).reshape(-1), _f32(verts).reshape(-1)
     F = len(faces) // 3
@@ -102,13 +113,18 @@ def grid_perspective(cc, faces, verts, nbx, nby, rows=None):
     zmin = np.zeros(F, np.float32)
     _lib.orc_persp_ranges(_p(_f32(cc)), _p(faces), _p(verts), C.c_int(F), C.c_int(nbx), C.c_int(nby), C.c_int(lo),
                           C.c_int(hi), _p(rng), _p(sizes), _p(zmin))
-    g = _finish_grid(lambda scan, k, v: _lib.orc_fill_2d(_p(rng), _p(scan), C.c_int(F), C.c_int(nby), _p(k), _p(v)),
-                     sizes, F, nbx * nby, nbx * nby)
+    if slabs > 1:
+        fill, zlist, zr = _slab_fill(rng, zmin, F, nby, slabs, (2.0, -2.0))
+        g = _finish_grid(fill, sizes, F, nbx * nby * slabs, nbx * nby * slabs)
+        g["zlist"], g["zrange"] = zlist, zr
+    else:
+        g = _finish_grid(lambda scan, k, v: _lib.orc_fill_2d(_p(rng), _p(scan), C.c_int(F), C.c_int(nby), _p(k), _p(v)),
+                         sizes, F, nbx * nby, nbx * nby)
     g["rng"], g["zmin"] = rng, zmin
     return g
 
 
-def grid_spherical(cc, faces, verts, lnbx, lnby, xM=PI_F, yM=PI_F):
+def grid_spherical(cc, faces, verts, lnbx, lnby, xM=PI_F, yM=PI_F, slabs=1):
     """FrustumGrid::buildSphericalGrid, frustum_grid.h:368-532."""
     faces, verts = _i32(faces).reshape(-1), _f32(verts).reshape(-1)
     F = len(faces) // 3
@@ -117,9 +133,14 @@ def grid_spherical(cc, faces, verts, lnbx, lnby, xM=PI_F, yM=PI_F):
     zmin = np.zeros(F, np.float32)
     _lib.orc_sph_ranges(_p(_f32(cc)), _p(faces), _p(verts), C.c_int(F), C.c_int(lnbx), C.c_int(lnby),
                         C.c_float(xM), C.c_float(yM), _p(rng), _p(sizes), _p(zmin))
-    g = _finish_grid(lambda scan, k, v: _lib.orc_fill_2d(_p(rng), _p(scan), C.c_int(F), C.c_int(lnby), _p(k), _p(v)),
-                     sizes, F, lnbx * lnby, lnbx * lnby)
-    g["rng"] = rng
+    if slabs > 1:
+        fill, zlist, zr = _slab_fill(rng, zmin, F, lnby, slabs, (9999.9, -9999.9))
+        g = _finish_grid(fill, sizes, F, lnbx * lnby * slabs, lnbx * lnby * slabs)
+        g["zlist"], g["zrange"] = zlist, zr
+    else:
+        g = _finish_grid(lambda scan, k, v: _lib.orc_fill_2d(_p(rng), _p(scan), C.c_int(F), C.c_int(lnby), _p(k), _p(v)),
+                         sizes, F, lnbx * lnby, lnbx * lnby)
+    g["rng"], g["zmin"] = rng, zmin
     return g
 
 
@@ -144,13 +165,20 @@ def grid_uniform(faces, verts, bbmin, bbmax, dims):
     return g
 
 
-def trace_primary(cam, W, H, grid, verts, faces, rows=None, out=None):
+def trace_primary(cam, W, H, grid, verts, faces, rows=None, out=None, slabs=1):
     """rckernel_alpha, trace_kernel.cu:84-270."""
     nbx, nby = W // 8, H // 8
     lo, hi = rows if rows is not None else (0, nby)
     N = W * H
     o = out or dict(normal=np.zeros(3 * N, np.float32), t=np.zeros(N, np.float32), dir=np.zeros(3 * N, np.float32),
                     shadowed=np.zeros(N, np.int32), id=np.zeros(N, np.int32))
+    if slabs > 1:
+        _lib.orc_trace_primary_slabs(_p(cam.cc), _p(cam.tex), C.c_int(W), C.c_int(H), C.c_int(nbx), C.c_int(nby),
+                                     C.c_int(lo), C.c_int(hi), C.c_int(slabs), _p(grid["vals"]), _p(grid["span"]),
+                                     _p(grid["offset"]), _p(_f32(verts).reshape(-1)), _p(_i32(faces).reshape(-1)),
+                                     _p(o["normal"]), _p(o["t"]), _p(o["dir"]), _p(o["shadowed"]), _p(o["id"]))
+        o["mt_tests"], o["refs_staged"] = 0, 0
+        return o
     cnt = np.zeros(2, np.uint64)
     _lib.orc_trace_primary(_p(cam.cc), _p(cam.tex), C.c_int(W), C.c_int(H), C.c_int(nbx), C.c_int(nby), C.c_int(lo),
                            C.c_int(hi), _p(grid["vals"]), _p(grid["span"]), _p(grid["offset"]),
@@ -174,13 +202,13 @@ def process_rays(d_map, n, nkeys, cap):
 
 
 def trace_shadow(lcc, lgrid, C_light, verts, faces, t, dirs, is_shadowed, d_map, prefix, cam_pos, nchunks,
-                 launch_blocks, n, strict=True):
+                 launch_blocks, n, strict=True, slabs=1):
     cnt = np.zeros(2, np.uint64)
-    _lib.orc_trace_shadow(_p(_f32(lcc)), _p(lgrid["vals"]), _p(_f32(verts).reshape(-1)),
-                          _p(_i32(faces).reshape(-1)), _p(lgrid["span"]), _p(lgrid["offset"]), C.c_uint(C_light),
-                          _p(t), _p(dirs), _p(is_shadowed), _p(d_map), _p(prefix), _p(_f32(cam_pos)),
-                          C.c_uint(nchunks), C.c_uint(launch_blocks), C.c_int(n), C.c_int(1 if strict else 0),
-                          _p(cnt))
+    _lib.orc_trace_shadow_slabs(_p(_f32(lcc)), _p(lgrid["vals"]), _p(_f32(verts).reshape(-1)),
+                                _p(_i32(faces).reshape(-1)), _p(lgrid["span"]), _p(lgrid["offset"]), C.c_uint(C_light),
+                                C.c_int(slabs), _p(t), _p(dirs), _p(is_shadowed), _p(d_map), _p(prefix),
+                                _p(_f32(cam_pos)), C.c_uint(nchunks), C.c_uint(launch_blocks), C.c_int(n),
+                                C.c_int(1 if strict else 0), _p(cnt))
     return int(cnt[0]), int(cnt[1])
 
 
@@ -256,7 +284,7 @@ def shade_reflect(cc, light_pos, img, normal, t, dirs, ids, cam_pos, mat_idx, ma
 
 
 def frame(scene, setup, W, H, rows=None, light_grid=(128, 128), all_chunks=False, shadows=True, reflect=False,
-          uniform_dims=(64, 64, 32), frame_cnt=1, reflect_eps=1e-3, verts=None):
+          uniform_dims=(64, 64, 32), frame_cnt=1, reflect_eps=1e-3, verts=None, slabs=1):
     """display(), main.cu:59-302, on the CPU.  Returns every intermediate array and, in
     r["times"], the seconds spent per stage (used by bench.py's cpu_baseline leg)."""
     import time as _time
@@ -282,9 +310,9 @@ def frame(scene, setup, W, H, rows=None, light_grid=(128, 128), all_chunks=False
     cam = cam_from(setup.camera, setup.fovy, aspect)
     r = dict(cam=cam, p0=p0, n=n, times=times)
     with _T("build_perspective"):
-        r["grid"] = grid_perspective(cam.cc, faces, verts, nbx, nby, (lo, hi))
+        r["grid"] = grid_perspective(cam.cc, faces, verts, nbx, nby, (lo, hi), slabs=slabs)
     with _T("trace_primary"):
-        r["primary"] = trace_primary(cam, W, H, r["grid"], verts, faces, (lo, hi))
+        r["primary"] = trace_primary(cam, W, H, r["grid"], verts, faces, (lo, hi), slabs=slabs)
     pr = r["primary"]
     cam_pos = cam.worldori[:3].copy()
     is_shadowed = pr["shadowed"].copy()
@@ -298,14 +326,14 @@ def frame(scene, setup, W, H, rows=None, light_grid=(128, 128), all_chunks=False
             d_map = map_rays(lcam.cc, pr["t"], pr["dir"], cam_pos, lx, ly, p0, n)
         r["map_unsorted"] = d_map.copy()
         with _T("build_spherical"):
-            r["lgrid"] = grid_spherical(lcam.cc, faces, verts, lx, ly)
+            r["lgrid"] = grid_spherical(lcam.cc, faces, verts, lx, ly, slabs=slabs)
         with _T("sort_rays"):
             prefix, nchunks = process_rays(d_map, n, lx * ly + 1, n // 64 + lx * ly + 2)
         r["map"], r["prefix"], r["nchunks"] = d_map, prefix, nchunks
         with _T("trace_shadow"):
             r["shadow_tests"] = trace_shadow(lcam.cc, r["lgrid"], lx * ly, verts, faces, pr["t"], pr["dir"],
                                              is_shadowed, d_map, prefix, cam_pos, nchunks, nbx * nby, n,
-                                             strict=not all_chunks)
+                                             strict=not all_chunks, slabs=slabs)
     r["is_shadowed"] = is_shadowed
     img = np.zeros(3 * N, np.uint8)
     ids = pr["id"].copy()

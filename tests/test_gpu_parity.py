@@ -720,3 +720,42 @@ def test_overlapped_display_equals_sequential(ugrt, O, torch):
         np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8), err_msg=name)
     want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud)
     np.testing.assert_array_equal(r2.image.cpu().numpy(), want["image"])
+
+
+@pytest.mark.parametrize("name,cam,W,H,lg", [("hall", "ref", 256, 256, (64, 64)), ("crash", "ref", 256, 144, (128, 128)),
+                                             ("cornell", "B", 256, 256, (32, 32))])
+@pytest.mark.parametrize("slabs", [2, 4])
+def test_z_slabs(ugrt, O, torch, name, cam, W, H, lg, slabs):
+    """NUM_SLABS > 1 (main.cu.h:18): projCoordZ, the zMin/zMax loop (frustum_grid.h:221-241), SlabKernel
+    (grid_kernel.cu:334), slab keys in both grids, the slab walk of rckernel_alpha (trace_kernel.cu:132-229) with
+    its state machine as written, the light kernel over all slabs of a cell (light_kernel.cu:105)."""
+    s = scene(ugrt, name)
+    setup = setup_for(ugrt, s, cam)
+    for all_chunks in (False, True):
+        flags = ugrt.FLAG_SHADOW_ALL_CHUNKS if all_chunks else 0
+        ctx = ugrt.Context(W, H, light_grid=lg, flags=flags, uniform_dims=(32, 32, 16), slabs=slabs)
+        r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+        r.display(setup, frame_cnt=1, shadows=True)
+        ctx.synchronize()
+        want = O.frame(s, setup, W, H, light_grid=lg, all_chunks=all_chunks, slabs=slabs)
+        for which, key in ((ugrt.GRID_PERSPECTIVE, "grid"), (ugrt.GRID_SPHERICAL, "lgrid")):
+            # the renderer rebuilt the perspective grid last with the light camera?  no: one build each per frame
+            value, keys, span, offset, gi = ctx.grid_arrays(which)
+            g = want[key]
+            assert gi.num_cells == len(g["span"]) and gi.total_refs == g["R"]
+            np.testing.assert_array_equal(u32(keys), g["keys"])
+            np.testing.assert_array_equal(u32(value), g["vals"])
+            np.testing.assert_array_equal(u32(span), g["span"])
+            np.testing.assert_array_equal(u32(offset), g["offset"])
+            si = ctx.grid_slabs(which)
+            assert si.slabs == slabs
+            assert_bits_equal(np.array([si.z_min, si.z_max], np.float32), np.array(g["zrange"], np.float32), "zMin/zMax")
+            pz = ctx.wrap_u32(si.d_proj_coord_z, len(g["zmin"]))
+            np.testing.assert_array_equal(u32(pz), bits(g["zmin"]))
+        pr = want["primary"]
+        np.testing.assert_array_equal(r.t.cpu().numpy().view(np.uint32), bits(pr["t"]))
+        assert_bits_equal(r.normal.cpu().numpy(), pr["normal"], "normal")
+        np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"])
+        np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"])
+        np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+        assert (pr["id"] >= 0).sum() > 0

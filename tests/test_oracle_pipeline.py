@@ -117,3 +117,33 @@ def test_empty_and_degenerate_inputs(ugrt, O):
     assert g2["R"] == 0 and g2["span"].sum() == 0
     out2 = O.trace_primary(cam, 64, 64, g2, verts, faces[:1], rows=(0, 2))
     assert (out2["id"][:2 * 8 * 64] == -2).all() and (out2["t"][:2 * 8 * 64] == -1).all()
+
+
+def test_slabs_one_equals_the_unslabbed_path(O, ugrt):
+    """orc_trace_primary_slabs with one slab is orc_trace_primary; with more slabs the light kernel's flags stay
+    those of the unslabbed light grid (a cell's slabs partition its list, light_kernel.cu:105-113)."""
+    s = ugrt.scenes.hall(scale=0.05)
+    setup = ugrt.FrameSetup(s["cameras"]["ref"], s["light_camera"], s["shading_light"])
+    W = H = 128
+    a = O.frame(s, setup, W, H, light_grid=(32, 32), all_chunks=True)
+    cam = a["cam"]
+    g1 = O.grid_perspective(cam.cc, s["faces"], s["verts"], W // 8, H // 8)
+    import numpy as np
+    o = dict(normal=np.zeros(3 * W * H, np.float32), t=np.zeros(W * H, np.float32), dir=np.zeros(3 * W * H, np.float32),
+             shadowed=np.zeros(W * H, np.int32), id=np.zeros(W * H, np.int32))
+    O._lib.orc_trace_primary_slabs(O._p(cam.cc), O._p(cam.tex), W, H, W // 8, H // 8, 0, H // 8, 1, O._p(g1["vals"]),
+                                   O._p(g1["span"]), O._p(g1["offset"]), O._p(O._f32(s["verts"]).reshape(-1)),
+                                   O._p(O._i32(s["faces"]).reshape(-1)), O._p(o["normal"]), O._p(o["t"]), O._p(o["dir"]),
+                                   O._p(o["shadowed"]), O._p(o["id"]))
+    np.testing.assert_array_equal(o["id"], a["primary"]["id"])
+    np.testing.assert_array_equal(o["t"].view(np.uint32), a["primary"]["t"].view(np.uint32))
+    b = O.frame(s, setup, W, H, light_grid=(32, 32), all_chunks=True, slabs=4)
+    # every triangle sits in exactly one slab of each cell it covers
+    assert b["grid"]["R"] == a["grid"]["R"] and b["lgrid"]["R"] == a["lgrid"]["R"]
+    assert len(b["grid"]["span"]) == 4 * len(a["grid"]["span"])
+    sp4 = b["lgrid"]["span"].reshape(-1, 4).sum(1)
+    np.testing.assert_array_equal(sp4, a["lgrid"]["span"])
+    # the slab walk accepts a hit only in the slab of its ndc depth and drops accepted rays of a tile that goes on:
+    # it never finds MORE hits than the single-slab walk, and the scene keeps some
+    hit4, hit1 = b["primary"]["id"] >= 0, a["primary"]["id"] >= 0
+    assert hit4.sum() > 0 and not (hit4 & ~hit1).any()

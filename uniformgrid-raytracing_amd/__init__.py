@@ -82,6 +82,10 @@ class GridInfo(C.Structure):
     ]
 
 
+class SlabInfo(C.Structure):
+    _fields_ = [("slabs", C.c_int), ("d_proj_coord_z", C.c_void_p), ("z_min", C.c_float), ("z_max", C.c_float)]
+
+
 _P = C.c_void_p
 _F3 = C.POINTER(C.c_float)
 
@@ -118,6 +122,7 @@ PROTOTYPES = {
     "ugrt_grid_build_spherical": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_float]),
     "ugrt_grid_build_uniform": (C.c_int, [_P, _P, _P, C.c_int, _F3, _F3]),
     "ugrt_grid_get_info": (C.c_int, [_P, C.c_int, C.POINTER(GridInfo)]),
+    "ugrt_grid_get_slabs": (C.c_int, [_P, C.c_int, C.POINTER(SlabInfo)]),
     "ugrt_geometry_changed": (C.c_int, [_P]),
     "ugrt_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int]),
     "ugrt_trace_primary": (C.c_int, [_P] * 11),

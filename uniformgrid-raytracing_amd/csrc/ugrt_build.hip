@@ -74,7 +74,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_persp(CamBlock cam, con
 								const float *__restrict__ verts, int F,
 								int gy_lo, int gy_hi, Rng *__restrict__ rng,
 								u32 *__restrict__ sizes, u32 *__restrict__ wide,
-								u32 *__restrict__ wcount)
+								u32 *__restrict__ wcount, float *__restrict__ projz)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (f >= F)
@@ -108,11 +108,14 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_persp(CamBlock cam, con
 	r.x = (u32)gxmin | ((u32)gxmax << 16);
 	r.y = (u32)gymin | ((u32)gymax << 16);
 	r.z = 0;
-	size = d_split_wide(f, dup ? 0u : size, (u32)(nbx * (gy_hi - gy_lo)), wide, wcount);
+	// (with z-slabs a triangle lies in ONE slab of every cell it covers: no wide list then)
+	size = d_split_wide(f, dup ? 0u : size, projz ? 0u : (u32)(nbx * (gy_hi - gy_lo)), wide, wcount);
 	if (dup)
 		return;
 	rng[f] = r;
 	sizes[f] = size;
+	if (projz)
+		projz[f] = d_min3(v1[2], v2[2], v3[2]); // projCoordZ, grid_kernel.cu:203,212
 }
 
 // DS_spherical_Kernel, grid_kernel.cu:481-659
@@ -120,13 +123,14 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const
 							      const float *__restrict__ verts, int F, int lnbx,
 							      int lnby, float xM, float yM, Rng *__restrict__ rng,
 							      u32 *__restrict__ sizes, u32 *__restrict__ wide,
-							      u32 *__restrict__ wcount)
+							      u32 *__restrict__ wcount, float *__restrict__ projz)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (f >= F)
 		f = F - 1;
 	const bool dup = (int)(blockIdx.x * BUILD_THREADS + threadIdx.x) >= F;
 	int blx[3], bly[3];
+	float rad[3];
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
 		int idx = 3 * faces[f * 3 + k];
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const
 		point[1] = verts[idx + 1] - cam.cc[1];
 		point[2] = verts[idx + 2] - cam.cc[2];
 		float radius = d_magnitude(point);
+		rad[k] = radius;
 		point[0] /= radius;
 		point[1] /= radius;
 		point[2] /= radius;
@@ -150,11 +155,123 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const
 	r.y = (u32)gymin | ((u32)gymax << 16);
 	r.z = 0;
 	u32 size = (u32)((gxmax - gxmin + 1) * (gymax - gymin + 1));
-	size = d_split_wide(f, dup ? 0u : size, (u32)(lnbx * lnby), wide, wcount);
+	size = d_split_wide(f, dup ? 0u : size, projz ? 0u : (u32)(lnbx * lnby), wide, wcount);
 	if (dup)
 		return;
 	rng[f] = r;
 	sizes[f] = size;
+	if (projz)
+		projz[f] = d_min3(rad[0], rad[1], rad[2]); // grid_kernel.cu:617-618,651
+}
+
+// ---------------------------------------------------------------------------
+// z-slabs (NUM_SLABS > 1): the host loop over h_projCoordZ (frustum_grid.h:221-241, :384-404) as a reduction,
+// then SlabKernel (grid_kernel.cu:334-352).  zr[0], zr[1] hold zMin, zMax as order-preserving integers.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int d_ordered_f(float f)
+{
+	const int b = __float_as_int(f);
+	return b ^ ((b >> 31) & 0x7FFFFFFF);
+}
+__device__ __forceinline__ float d_unordered_f(int b) { return __int_as_float(b ^ ((b >> 31) & 0x7FFFFFFF)); }
+
+__global__ void k_zrange_init(int *__restrict__ zr, float zmin_init, float zmax_init)
+{
+	zr[0] = d_ordered_f(zmin_init);
+	zr[1] = d_ordered_f(zmax_init);
+}
+
+// zMin = smallest value >= 0 (or the initial value), zMax = largest value (NaNs never win a comparison of the
+// host loop, so they are left out)
+__global__ __launch_bounds__(BUILD_THREADS) void k_zrange(const float *__restrict__ projz, int F, int *__restrict__ zr)
+{
+	int lo = 0x7FFFFFFF, hi = (int)0x80000000;
+	for (int f = blockIdx.x * BUILD_THREADS + threadIdx.x; f < F; f += gridDim.x * BUILD_THREADS) {
+		const float z = projz[f];
+		if (z >= 0.0f) {
+			const int o = d_ordered_f(z);
+			lo = o < lo ? o : lo;
+		}
+		if (z == z) {
+			const int o = d_ordered_f(z);
+			hi = o > hi ? o : hi;
+		}
+	}
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1) {
+		const int ol = __shfl_xor(lo, m), oh = __shfl_xor(hi, m);
+		lo = ol < lo ? ol : lo;
+		hi = oh > hi ? oh : hi;
+	}
+	if ((threadIdx.x & 63) == 0) {
+		if (lo != 0x7FFFFFFF)
+			atomicMin(&zr[0], lo);
+		if (hi != (int)0x80000000)
+			atomicMax(&zr[1], hi);
+	}
+}
+
+// SlabKernel; a triangle with a negative depth keeps slab 0 (the reference leaves its entry uninitialised,
+// SURVEY.md Q20).  The slab goes into the z range of the triangle's cell box: the fill then writes
+// key = (gx*ny + gy)*slabs + slab (grid_kernel.cu:310,322).
+__global__ __launch_bounds__(BUILD_THREADS) void k_slab(const float *__restrict__ projz, int F, int slabs,
+							 const int *__restrict__ zr, Rng *__restrict__ rng)
+{
+	const int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (f >= F)
+		return;
+	const float zMin = d_unordered_f(zr[0]), zMax = d_unordered_f(zr[1]);
+	const float pCoord = projz[f];
+	u32 binID = 0;
+	if (pCoord >= 0.0f) {
+		binID = ugrt_f2u((float)slabs * (float)((pCoord - zMin) / (zMax - zMin)));
+		if (binID >= (u32)slabs)
+			binID = (u32)slabs - 1u;
+	}
+	rng[f].z = binID | (binID << 16);
+}
+
+// span/offset of a light cell's slabs taken together: a cell's runs are adjacent in the sorted lists
+__global__ __launch_bounds__(BUILD_THREADS) void k_slab_union(const u32 *__restrict__ span, const u32 *__restrict__ offset,
+							       u32 C, u32 slabs, u32 *__restrict__ uspan,
+							       u32 *__restrict__ uoffset)
+{
+	const u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (c >= C)
+		return;
+	const u32 first = c * slabs, last = first + slabs - 1u;
+	uoffset[c] = offset[first];
+	uspan[c] = offset[last] + span[last] - offset[first];
+}
+
+int ugrt_slab_union(ugrt_ctx *ctx, const u32 *d_span, const u32 *d_offset, u32 C, u32 slabs, const u32 **uspan,
+		    const u32 **uoffset)
+{
+	Grid &G = ctx->grid[UGRT_GRID_SPHERICAL];
+	int rc = ugrt_buf_reserve(ctx, G.uspan, (size_t)C * 8);
+	if (rc)
+		return rc;
+	u32 *us = (u32 *)G.uspan.p, *uo = us + C;
+	hipLaunchKernelGGL(k_slab_union, dim3((C + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, ctx->stream,
+			   d_span, d_offset, C, slabs, us, uo);
+	UGRT_HIP(hipGetLastError());
+	*uspan = us;
+	*uoffset = uo;
+	return UGRT_OK;
+}
+
+// the slab stage between the count kernel and the scan/fill
+static int build_slabs(ugrt_ctx *ctx, Grid &G, int F, float zmin_init, float zmax_init)
+{
+	int *zr = (int *)((float *)G.projz.p + F);
+	hipLaunchKernelGGL(k_zrange_init, dim3(1), dim3(1), 0, ctx->stream, zr, zmin_init, zmax_init);
+	int blocks = (F + BUILD_THREADS - 1) / BUILD_THREADS;
+	hipLaunchKernelGGL(k_zrange, dim3(blocks < 1024 ? blocks : 1024), dim3(BUILD_THREADS), 0, ctx->stream,
+			   (const float *)G.projz.p, F, zr);
+	hipLaunchKernelGGL(k_slab, dim3(blocks), dim3(BUILD_THREADS), 0, ctx->stream, (const float *)G.projz.p, F,
+			   ctx->cfg.slabs, (const int *)zr, (Rng *)G.rng.p);
+	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
 }
 
 struct UGrid {
@@ -456,6 +573,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	int rc;
 	G.valid = false;
 	G.C = C;
+	G.F = F;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SCAN);
 	rc = ugrt_prim_inclusive_scan(ctx, (const u32 *)G.sizes.p, (u32 *)G.scan.p, (size_t)F);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_SCAN);
@@ -605,16 +723,23 @@ extern "C" int ugrt_grid_build_perspective(ugrt_ctx *ctx, const int *d_facelist,
 	int rc = build_prologue(ctx, G, d_facelist, d_vertlist, F, "grid_build_perspective");
 	if (rc)
 		return rc;
+	const int K = ctx->cfg.slabs;
+	G.slabs = K;
+	if (K > 1 && (rc = ugrt_buf_reserve(ctx, G.projz, (size_t)F * 4 + 8)))
+		return rc;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_persp, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, ctx->cfg.row_begin, ctx->cfg.row_end,
-			   (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F));
-	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
+			   (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F),
+			   K > 1 ? (float *)G.projz.p : (float *)nullptr);
 	UGRT_HIP(hipGetLastError());
+	if (K > 1 && (rc = build_slabs(ctx, G, F, 2.0f, -2.0f))) // frustum_grid.h:223
+		return rc;
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	G.dims[0] = ctx->nbx;
 	G.dims[1] = ctx->nby;
-	G.dims[2] = 1;
-	return build_common(ctx, G, F, (u32)ctx->nbx * (u32)ctx->nby, ctx->nby, 1, ctx->cfg.row_begin,
+	G.dims[2] = K;
+	return build_common(ctx, G, F, (u32)ctx->nbx * (u32)ctx->nby * (u32)K, ctx->nby, K, ctx->cfg.row_begin,
 			    ctx->cfg.row_end - 1);
 }
 
@@ -627,16 +752,23 @@ extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, c
 	if (rc)
 		return rc;
 	int lx = ctx->cfg.light_nbx, ly = ctx->cfg.light_nby;
+	const int K = ctx->cfg.slabs;
+	G.slabs = K;
+	if (K > 1 && (rc = ugrt_buf_reserve(ctx, G.projz, (size_t)F * 4 + 8)))
+		return rc;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_sph, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, lx, ly, xM, yM, (Rng *)G.rng.p,
-			   (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F));
-	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
+			   (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F),
+			   K > 1 ? (float *)G.projz.p : (float *)nullptr);
 	UGRT_HIP(hipGetLastError());
+	if (K > 1 && (rc = build_slabs(ctx, G, F, 9999.9f, -9999.9f))) // frustum_grid.h:386
+		return rc;
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	G.dims[0] = lx;
 	G.dims[1] = ly;
-	G.dims[2] = 1;
-	return build_common(ctx, G, F, (u32)lx * (u32)ly, ly, 1, 0, ly - 1);
+	G.dims[2] = K;
+	return build_common(ctx, G, F, (u32)lx * (u32)ly * (u32)K, ly, K, 0, ly - 1);
 }
 
 // uniform grid over the scene box (Model::{x,y,z}{Min,Max}, scene.h:273-292),

@@ -57,8 +57,8 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 		return rc;
 	if (cfg->tile != 8)
 		return ugrt_fail(UGRT_EINVAL, "tile must be 8 (one 8x8 tile = one wavefront; main.cu.h:25-26)");
-	if (cfg->slabs != 1)
-		return ugrt_fail(UGRT_EINVAL, "slabs must be 1 (NUM_SLABS, main.cu.h:18)");
+	if (cfg->slabs < 1 || cfg->slabs > 64)
+		return ugrt_fail(UGRT_EINVAL, "slabs must be within [1,64] (NUM_SLABS, main.cu.h:18)");
 	if (cfg->width <= 0 || cfg->height <= 0 || cfg->width % 8 || cfg->height % 8)
 		return ugrt_fail(UGRT_EINVAL, "width and height must be positive multiples of 8");
 	int nbx = cfg->width / 8, nby = cfg->height / 8;
@@ -128,6 +128,8 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 		buf_free(G.val[1]);
 		buf_free(G.span);
 		buf_free(G.offset);
+		buf_free(G.projz);
+		buf_free(G.uspan);
 		}
 	buf_free(ctx->temp);
 	buf_free(ctx->rs_state);
@@ -277,6 +279,33 @@ extern "C" int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out)
 	out->total_refs = G.R;
 	out->num_cells = G.C;
 	out->cells_used = ctx->h_pinned[4 + which];
+	return UGRT_OK;
+}
+
+// the z-slab stage of a build: DSKernel's projCoordZ, the host loop's zMin/zMax (frustum_grid.h:221-241),
+// SlabKernel's zList
+extern "C" int ugrt_grid_get_slabs(ugrt_ctx *ctx, int which, ugrt_slab_info *out)
+{
+	if (!ctx || !out || which < 0 || which > 1)
+		return ugrt_fail(UGRT_EINVAL, "grid_get_slabs: bad argument (the perspective and the spherical grid have slabs)");
+	Grid &G = ctx->grid[which];
+	if (!G.valid)
+		return ugrt_fail(UGRT_EINVAL, "grid_get_slabs: grid %d has not been built", which);
+	out->slabs = G.slabs;
+	out->d_proj_coord_z = nullptr;
+	out->z_min = out->z_max = 0.0f;
+	if (G.slabs > 1) {
+		int z[2];
+		UGRT_HIP(hipSetDevice(ctx->device));
+		UGRT_HIP(hipMemcpyAsync(z, (const char *)G.projz.p + (size_t)G.F * 4, 8, hipMemcpyDeviceToHost,
+					ctx->stream));
+		UGRT_HIP(hipStreamSynchronize(ctx->stream));
+		for (int k = 0; k < 2; k++) {
+			const int b = z[k] ^ ((z[k] >> 31) & 0x7FFFFFFF);
+			memcpy(k ? &out->z_max : &out->z_min, &b, 4);
+		}
+		out->d_proj_coord_z = (float *)G.projz.p;
+	}
 	return UGRT_OK;
 }
 

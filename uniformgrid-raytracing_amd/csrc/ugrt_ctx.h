@@ -46,6 +46,9 @@ struct Grid {
 	DevBuf wide;                      // ids of the triangles that cover every cell: [F] as found, [F] ascending
 	DevBuf key[2], val[2];            // per ref, ping-pong for the radix sort
 	DevBuf span, offset;              // per cell (span buffer also holds run starts + cells_used)
+	DevBuf projz;                     // NUM_SLABS > 1: projCoordZ per triangle, then {zMin, zMax} as ordered integers
+	DevBuf uspan;                     // NUM_SLABS > 1: span/offset of a cell's slabs taken together (shadow tracer)
+	int slabs = 1, F = 0;
 	u32 *keys = nullptr, *vals = nullptr; // sorted result (one of key[i]/val[i])
 	u32 R = 0, C = 0, cells_used = 0;
 	int dims[3] = { 0, 0, 0 };
@@ -111,6 +114,9 @@ struct ugrt_ctx {
 	} while (0)
 
 int ugrt_buf_reserve(ugrt_ctx *ctx, DevBuf &b, size_t bytes);
+// NUM_SLABS > 1: span/offset over all slabs of each of the C light cells (ugrt_build.hip)
+int ugrt_slab_union(ugrt_ctx *ctx, const u32 *d_span, const u32 *d_offset, u32 C, u32 slabs, const u32 **uspan,
+		    const u32 **uoffset);
 float *ugrt_ctx_tex(ugrt_ctx *ctx); // device copy of the 5x5x4 direction table
 static inline u32 *ugrt_wide_counter(ugrt_ctx *ctx) { return ctx->d_small + 3; } // wide triangles of the running build
 void ugrt_prof_begin(ugrt_ctx *ctx, int stage);

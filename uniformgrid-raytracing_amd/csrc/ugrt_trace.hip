@@ -254,6 +254,119 @@ __global__ __launch_bounds__(64, 5) void k_trace_primary(CamBlock cam, const flo
 	}
 }
 
+// rckernel_alpha with NUM_SLABS > 1 (trace_kernel.cu:132-229): one wave per tile walks the tile's slabs front to
+// back.  The reference's state machine is kept as written: a hit is accepted (rayDone = 2) in the slab whose
+// index equals floor(ndc_z * slabs); accepted rays skip the tests of the next slab; isWithin then returns 0 for
+// them (:59-62), i.e. they fall back to "no hit" with their oldt kept; the tile stops once all 64 rays are
+// accepted.  Lists are culled per batch against the tile's direction box (survivors keep the list order).
+template <bool REC>
+__global__ __launch_bounds__(64) void k_trace_primary_slabs(CamBlock cam, const float *__restrict__ tex, int slabs,
+							     int gy_lo, int rows, u32 ntiles,
+							     const u32 *__restrict__ span, const u32 *__restrict__ offset,
+							     const u32 *__restrict__ value_list,
+							     const float *__restrict__ verts, const int *__restrict__ tris,
+							     const float4 *__restrict__ rec, PrimaryOut out)
+{
+	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
+	const int lane = threadIdx.x;
+	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
+	for (u32 it = d_xcd_block(); it < ntiles; it += gridDim.x) {
+		const int bx = (int)(it / (u32)rows), by = gy_lo + (int)(it % (u32)rows);
+		const u32 cell = (u32)bx * (u32)cam.nby + (u32)by;
+		const int col = bx * 8 + (lane & 7), row = by * 8 + (lane >> 3);
+		const int pixelID = row * cam.W + col;
+		float dir[3];
+		d_ray_dir(cam, tex, col, row, dir);
+		CBox tb;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			const float lo = d_wave_fmin(dir[k]), hi = d_wave_fmax(dir[k]);
+			tb.c[k] = 0.5f * (lo + hi);
+			tb.r[k] = 0.5f * (hi - lo) * 1.0001f + 1e-6f;
+		}
+		float oldt = 99999999.9f;
+		u32 ref = 0xFFFFFFFFu;
+		int rayDone = 0;
+		for (int slab = 0; slab < slabs; slab++) {
+			const u32 sp = span[cell * (u32)slabs + (u32)slab], off = offset[cell * (u32)slabs + (u32)slab];
+			for (u32 b = 0; b < sp; b += 64u) {
+				const u32 cnt = (sp - b) < 64u ? (sp - b) : 64u;
+				bool keep = false;
+				float t9[9];
+				if ((u32)lane < cnt) {
+					d_load_triangle<REC>(rec, verts, tris, value_list[off + b + lane], ex, ey, ez, t9);
+					const CullTri ct = d_cull_prep(&t9[0], &t9[3], &t9[6]);
+					keep = !d_cull_cr(ct, tb);
+				}
+				const unsigned long long mask = __ballot(keep);
+				const u32 nsurv = (u32)__popcll(mask);
+				__syncthreads();
+				if (keep) {
+					float4 *dst = reinterpret_cast<float4 *>(&lds[d_rank_in_mask(mask) * TRI_STRIDE]);
+					dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
+					dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
+					dst[2] = make_float4(t9[8], __uint_as_float(off + b + lane), 0.0f, 0.0f);
+				}
+				__syncthreads();
+				if (rayDone != 2) {
+					for (u32 k = 0; k < nsurv; k++) {
+						const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
+						const float4 a = src[0], c = src[1], e = src[2];
+						const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
+						const float v = d_intersect_tri_uv(tv, e1, e2, dir, oldt);
+						if (v != 0.0f) {
+							oldt = v;
+							rayDone = 1;
+							ref = __float_as_uint(e.y);
+						}
+					}
+				}
+			}
+			// isWithin, trace_kernel.cu:56-82
+			if (rayDone == 0 || rayDone == 2) {
+				rayDone = 0;
+			} else {
+				const float px = ex + oldt * dir[0], py = ey + oldt * dir[1], pz = ez + oldt * dir[2];
+				const float *m = cam.cc;
+				float hz = D_MULMV_ROW(m, 48, 2, px, py, pz);
+				const float hw = D_MULMV_ROW(m, 48, 3, px, py, pz);
+				hz /= hw;
+				rayDone = ugrt_floor2i(hz * (float)slabs) == slab ? 2 : 1;
+			}
+			if (__ballot(rayDone != 2) == 0ull)
+				break; // the beam is done, trace_kernel.cu:217-228
+		}
+		if (rayDone == 2) {
+			const u32 face = value_list[ref];
+			float tri[9];
+			d_load_triangle<REC>(rec, verts, tris, face, 0.0f, 0.0f, 0.0f, tri);
+			float *e1 = &tri[3], *e2 = &tri[6], nrm[3];
+			D_NORMALIZE(e1);
+			D_NORMALIZE(e2);
+			D_CROSS(nrm, e1, e2);
+			D_NORMALIZE(nrm);
+			nrm[0] = nrm[0] < 0 ? nrm[0] * -1 : nrm[0];
+			nrm[1] = nrm[1] < 0 ? nrm[1] * -1 : nrm[1];
+			nrm[2] = nrm[2] < 0 ? nrm[2] * -1 : nrm[2];
+			out.t_value[pixelID] = oldt;
+			out.intersect_id[pixelID] = (int)face;
+			out.normal[pixelID * 3 + 0] = nrm[0];
+			out.normal[pixelID * 3 + 1] = nrm[1];
+			out.normal[pixelID * 3 + 2] = nrm[2];
+		} else {
+			out.t_value[pixelID] = -1.0f;
+			out.intersect_id[pixelID] = -2;
+			out.normal[pixelID * 3 + 0] = -1.0f;
+			out.normal[pixelID * 3 + 1] = -1.0f;
+			out.normal[pixelID * 3 + 2] = -1.0f;
+		}
+		out.shadowed[pixelID] = 0;
+		out.ray_dir[pixelID * 3 + 0] = dir[0];
+		out.ray_dir[pixelID * 3 + 1] = dir[1];
+		out.ray_dir[pixelID * 3 + 2] = dir[2];
+	}
+}
+
 // pixels of split cells: take the merged (t, ref), finish, re-arm the slot
 template <bool REC>
 __global__ __launch_bounds__(256) void k_resolve_primary(CamBlock cam, const float *__restrict__ tex,
@@ -312,6 +425,22 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	const int rows = ctx->cfg.row_end - ctx->cfg.row_begin;
 	const u32 ncell = (u32)ctx->nbx * (u32)rows;
 	const u32 C = (u32)ctx->nbx * (u32)ctx->nby;
+	if (ctx->cfg.slabs > 1) { // NUM_SLABS > 1: the slab walk of trace_kernel.cu:132-229, one wave per tile
+		PrimaryOut o = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
+		const bool rec_ok = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
+		ugrt_prof_begin(ctx, UGRT_ST_TRACE_PRIMARY);
+		if (rec_ok)
+			hipLaunchKernelGGL(k_trace_primary_slabs<true>, dim3(launch_blocks_for(ncell)), dim3(64), 0, st, ctx->cam,
+					   (const float *)ugrt_ctx_tex(ctx), ctx->cfg.slabs, ctx->cfg.row_begin, rows, ncell, d_span,
+					   d_offset, d_value_list, d_vertlist, d_trilist, (const float4 *)ctx->trirec.p, o);
+		else
+			hipLaunchKernelGGL(k_trace_primary_slabs<false>, dim3(launch_blocks_for(ncell)), dim3(64), 0, st, ctx->cam,
+					   (const float *)ugrt_ctx_tex(ctx), ctx->cfg.slabs, ctx->cfg.row_begin, rows, ncell, d_span,
+					   d_offset, d_value_list, d_vertlist, d_trilist, (const float4 *)nullptr, o);
+		ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
+		UGRT_HIP(hipGetLastError());
+		return UGRT_OK;
+	}
 	u32 R = 0;
 	int rc = refs_of(ctx, d_span, d_offset, C, &R);
 	if (rc)
@@ -1003,6 +1132,11 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
 	const float4 *rec = use_rec ? (const float4 *)ctx->trirec.p : (const float4 *)nullptr;
 	int rc;
+	// NUM_SLABS > 1: span/offset hold C * slabs entries; the block of a chunk walks all slabs of its cell
+	// (light_kernel.cu:105-113) and a ray is shadowed by an occluder in any of them: the cell's list is the
+	// union of its slabs' runs, which lie next to each other
+	if (ctx->cfg.slabs > 1 && (rc = ugrt_slab_union(ctx, d_span, d_offset, C, (u32)ctx->cfg.slabs, &d_span, &d_offset)))
+		return rc;
 	for (int i = 0; i < 2; i++) {
 		if ((rc = ugrt_buf_reserve(ctx, ctx->skey[i], (size_t)n * 8)))
 			return rc;

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import lib, check, Config, GridInfo, STAGES, _f3, _P
+from . import lib, check, Config, GridInfo, SlabInfo, STAGES, _f3, _P
 
 
 def _ptr(t):
@@ -22,12 +22,12 @@ def _ptr(t):
 
 class Context:
     def __init__(self, width, height, device=0, light_grid=(128, 128), rows=None, flags=0,
-                 uniform_dims=(64, 64, 32)):
+                 uniform_dims=(64, 64, 32), slabs=1):
         import torch  # device memory, streams
 
         self.torch = torch
         cfg = Config()
-        cfg.width, cfg.height, cfg.tile, cfg.slabs = width, height, 8, 1
+        cfg.width, cfg.height, cfg.tile, cfg.slabs = width, height, 8, slabs
         cfg.light_nbx, cfg.light_nby = light_grid
         nby = height // 8
         cfg.row_begin, cfg.row_end = rows if rows is not None else (0, nby)
@@ -105,6 +105,11 @@ class Context:
         gi = GridInfo()
         check(lib.ugrt_grid_get_info(self._h, which, C.byref(gi)))
         return gi
+
+    def grid_slabs(self, which):
+        si = SlabInfo()
+        check(lib.ugrt_grid_get_slabs(self._h, which, C.byref(si)))
+        return si
 
     def grid_ptrs(self, which):
         """(value, span, offset) as raw device pointers + the GridInfo: what a frame loop passes on."""

@@ -61,7 +61,8 @@ class Renderer:
             with t.cuda.stream(self.aux_stream):
                 self.aux = Context(ctx.width, ctx.height, device=ctx.device_index, light_grid=ctx.light_grid,
                                    rows=ctx.rows, flags=int(ctx.cfg.flags),
-                                   uniform_dims=tuple(ctx.cfg.uniform_dims[k] for k in range(3)))
+                                   uniform_dims=tuple(ctx.cfg.uniform_dims[k] for k in range(3)),
+                                   slabs=int(ctx.cfg.slabs))
             # the bounce runs beside the shadow pass: fewer, fuller waves leave the main stream more of the chip
             self.aux.set_option("dda_rays_per_wave", 64)
             import queue

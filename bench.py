@@ -140,6 +140,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: every stage after the other (default: light/uniform grid builds and the bounce "
                          "on a second stream beside the camera and shadow passes)")
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE configs[3] as stated: ONE 3840x2160 frame cut into N bands (strong scaling)")
+    ap.add_argument("--shard-builds", action="store_true",
+                    help="the light grid and the uniform grid are built in N shards of the triangle list, exchanged "
+                         "and merged (SURVEY 8f.1; one-stream frame)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="launch-shape option for every context (ugrt_ctx_set_option), e.g. dda_kernel=1")
     ap.add_argument("--animate", action="store_true",
@@ -176,6 +181,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU: libugrt has no CPU fallback"
     torch.cuda.set_device(local)
 
+    if args.config3:
+        args.width, args.height = 3840, 2160
     if args.width and args.height:
         W, H = args.width, args.height
     elif args.workload == "hall":
@@ -191,8 +198,10 @@ def main():
     # the renderer is the only writer of the vertex array (ugrt_animate): triangle records survive between builds
     flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY
     ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
+    shards = parallel.GridShards(dist, torch, ctx.device, rank, world, host_staging=rehearse) \
+        if args.shard_builds else None
     r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
-                      overlap=not args.no_overlap)
+                      overlap=not args.no_overlap and shards is None, shards=shards)
     for kv in args.opt:
         k, v = kv.split("=")
         for c in [ctx] + ([r.aux] if r.aux is not None else []):
@@ -346,7 +355,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (world > 1 and args.width and args.height) else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a result)",
@@ -359,7 +368,9 @@ def main():
             "frames_per_s": round(args.steps / elapsed, 2),
             "rays_per_frame": int(rays_total),
             "tile": 8, "light_grid": list(lg), "uniform_grid": list(udims),
-            "streams": 1 if args.no_overlap else 2,
+            "streams": 1 if (args.no_overlap or args.shard_builds) else 2,
+            "grid_builds": "light + uniform grid in %d shards of the triangle list, all-gathered and merged" % world
+                           if args.shard_builds else "replicated per rank",
             "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",
         },
         "roofline": roofline,

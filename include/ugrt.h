@@ -211,6 +211,15 @@ int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out);
 /* With slabs > 1 the arrays of ugrt_grid_info hold num_cells = cells * slabs entries, cell-major
  * (key = cell * slabs + slab, grid_kernel.cu:322).  This call synchronises the stream. */
 int ugrt_grid_get_slabs(ugrt_ctx *ctx, int which, ugrt_slab_info *out);
+/* Sharded build of the light grid and the uniform grid across the GPUs of a node (not in the reference, which
+ * has one GPU).  Each rank restricts its builds to a window [begin, end) of the triangle list
+ * (end = 0: to the last triangle; 0, 0 restores the full build), the ranks exchange the arrays of their shards
+ * (ugrt_grid_get_info: keys, values, span; total_refs entries) and every rank merges them: part r must hold the
+ * window of rank r, windows ascending with r and disjoint.  The merged arrays become the context's grid and are
+ * element for element those of a full build.  The parts are the caller's buffers, not the context's arrays. */
+int ugrt_ctx_set_face_window(ugrt_ctx *ctx, int begin, int end);
+int ugrt_grid_merge_shards(ugrt_ctx *ctx, int which, int nparts, const unsigned *const *d_keys,
+			   const unsigned *const *d_vals, const unsigned *const *d_span, const unsigned *counts);
 /* with UGRT_FLAG_STATIC_GEOMETRY: the vertex or face array was rewritten by the caller */
 int ugrt_geometry_changed(ugrt_ctx *ctx);
 /* cudppSort(plan, keys, values, bits, n) with CUDPP_SORT_RADIX on (uint key, uint value) pairs

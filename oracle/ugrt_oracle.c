@@ -1528,6 +1528,8 @@ void orc_fill_3d(const int *rng6, const u32 *scanList, int F, const int *dims, u
 		u32 offset = f ? scanList[f - 1] : 0;
 		const int *r = rng6 + f * 6;
 		int sy = r[3] - r[2] + 1, sz = r[5] - r[4] + 1, i, j, k;
+		if (scanList[f] == offset)
+			continue; /* no references: outside this rank's window of a sharded build */
 		for (i = r[0]; i <= r[1]; i++)
 			for (j = r[2]; j <= r[3]; j++)
 				for (k = r[4]; k <= r[5]; k++) {

@@ -124,7 +124,14 @@ def grid_perspective(cc, faces, verts, nbx, nby, rows=None, slabs=1):
     return g
 
 
-def grid_spherical(cc, faces, verts, lnbx, lnby, xM=PI_F, yM=PI_F, slabs=1):
+def _apply_window(sizes, window):
+    """A shard of the build (multi-GPU, not in the reference): triangles outside [f0, f1) get no references."""
+    if window is not None:
+        sizes[:window[0]] = 0
+        sizes[window[1]:] = 0
+
+
+def grid_spherical(cc, faces, verts, lnbx, lnby, xM=PI_F, yM=PI_F, slabs=1, window=None):
     """FrustumGrid::buildSphericalGrid, frustum_grid.h:368-532."""
     faces, verts = _i32(faces).reshape(-1), _f32(verts).reshape(-1)
     F = len(faces) // 3
@@ -133,6 +140,7 @@ def grid_spherical(cc, faces, verts, lnbx, lnby, xM=PI_F, yM=PI_F, slabs=1):
     zmin = np.zeros(F, np.float32)
     _lib.orc_sph_ranges(_p(_f32(cc)), _p(faces), _p(verts), C.c_int(F), C.c_int(lnbx), C.c_int(lnby),
                         C.c_float(xM), C.c_float(yM), _p(rng), _p(sizes), _p(zmin))
+    _apply_window(sizes, window)
     if slabs > 1:
         fill, zlist, zr = _slab_fill(rng, zmin, F, lnby, slabs, (9999.9, -9999.9))
         g = _finish_grid(fill, sizes, F, lnbx * lnby * slabs, lnbx * lnby * slabs)
@@ -150,7 +158,7 @@ def uniform_setup(bbmin, bbmax, dims):
     return g
 
 
-def grid_uniform(faces, verts, bbmin, bbmax, dims):
+def grid_uniform(faces, verts, bbmin, bbmax, dims, window=None):
     faces, verts = _i32(faces).reshape(-1), _f32(verts).reshape(-1)
     F = len(faces) // 3
     dims = _i32(dims)
@@ -158,6 +166,7 @@ def grid_uniform(faces, verts, bbmin, bbmax, dims):
     rng = np.zeros(F * 6, np.int32)
     sizes = np.zeros(F, np.uint32)
     _lib.orc_uniform_ranges(_p(ug), _p(dims), _p(faces), _p(verts), C.c_int(F), _p(rng), _p(sizes))
+    _apply_window(sizes, window)
     ncell = int(dims[0]) * int(dims[1]) * int(dims[2])
     g = _finish_grid(lambda scan, k, v: _lib.orc_fill_3d(_p(rng), _p(scan), C.c_int(F), _p(dims), _p(k), _p(v)),
                      sizes, F, ncell, ncell)

@@ -80,3 +80,71 @@ def test_band_rows_partition(ugrt):
     for w in (2, 8):
         W, H = parallel.weak_scaling_resolution(w)
         assert W % 8 == 0 and H % 8 == 0 and abs(W * H / (1920 * 1080.0) - w) < 0.02 * w
+
+
+def _shard_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    import oracle_lib as O
+    import ugrt
+    from ugrt import parallel
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O.set_threads(2)
+        s = ugrt.scenes.hall(scale=0.05)
+        setup = ugrt.FrameSetup.from_scene(s)
+        F = s["num_faces"]
+        f0, f1 = parallel.face_window(rank, world, F)
+        lcam = O.cam_from(setup.light_camera, setup.fovy, 1.0)
+        v3 = np.asarray(s["verts"], np.float32).reshape(-1, 3)
+        out = {}
+        for name in ("light", "uniform"):
+            # this rank's shard: the oracle's builder on a scene in which every triangle outside the window is
+            # given no references (what ugrt_ctx_set_face_window does in the count kernels)
+            if name == "light":
+                g = O.grid_spherical(lcam.cc, s["faces"], s["verts"], 32, 32, window=(f0, f1))
+            else:
+                g = O.grid_uniform(s["faces"], s["verts"], v3.min(0), v3.max(0), (16, 16, 8), window=(f0, f1))
+            sh = parallel.GridShards(dist, torch, torch.device("cpu"), rank, world)
+            k = torch.from_numpy(g["keys"].view(np.int32).copy())
+            v = torch.from_numpy(g["vals"].view(np.int32).copy())
+            sp = torch.from_numpy(g["span"].view(np.int32).copy())
+            ks, vs, sps, counts = sh.exchange(k, v, sp, g["R"])
+            assert counts[rank] == g["R"]
+            mk, mv, msp, moff = parallel.merge_shards_numpy([x.numpy().view(np.uint32) for x in ks],
+                                                            [x.numpy().view(np.uint32) for x in vs],
+                                                            [x.numpy().view(np.uint32) for x in sps])
+            out[name] = (mk, mv, msp, moff)
+        dist.barrier()
+        np.savez(out_path % rank, **{"%s_%d" % (n, i): a for n, t in out.items() for i, a in enumerate(t)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_grid_build(tmp_path, ugrt, O):
+    """the light grid and the uniform grid are built in two shards of the triangle list, exchanged
+    over the process group and merged; on BOTH ranks the result is the single-rank build, element for element."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "grids_%d.npz")
+    mp.spawn(_shard_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    s = ugrt.scenes.hall(scale=0.05)
+    setup = ugrt.FrameSetup.from_scene(s)
+    lcam = O.cam_from(setup.light_camera, setup.fovy, 1.0)
+    v3 = np.asarray(s["verts"], np.float32).reshape(-1, 3)
+    want = {"light": O.grid_spherical(lcam.cc, s["faces"], s["verts"], 32, 32),
+            "uniform": O.grid_uniform(s["faces"], s["verts"], v3.min(0), v3.max(0), (16, 16, 8))}
+    for rank in (0, 1):
+        got = np.load(out % rank)
+        for name, g in want.items():
+            np.testing.assert_array_equal(got[name + "_0"], g["keys"])
+            np.testing.assert_array_equal(got[name + "_1"], g["vals"])
+            np.testing.assert_array_equal(got[name + "_2"], g["span"])
+            np.testing.assert_array_equal(got[name + "_3"], g["offset"])
+            assert g["R"] > 0

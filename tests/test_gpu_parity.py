@@ -759,3 +759,51 @@ def test_z_slabs(ugrt, O, torch, name, cam, W, H, lg, slabs):
         np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"])
         np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
         assert (pr["id"] >= 0).sum() > 0
+
+
+@pytest.mark.parametrize("name,nparts", [("hall", 2), ("crash", 3)])
+def test_sharded_grid_build_merge(ugrt, O, torch, name, nparts):
+    """SURVEY 8f.1 on the device: the light grid and the uniform grid are built in `nparts` windows of the
+    triangle list (what the ranks of a node do) and merged by ugrt_grid_merge_shards; keys, values, span, offset
+    and cells_used are those of the full build and of the oracle."""
+    from ugrt import parallel
+
+    s = scene(ugrt, name)
+    W, H, lg, udims = 256, 144, (64, 64), (32, 32, 16)
+    ctx, r = make(ugrt, s, W, H, lg, udims=udims)
+    setup = setup_for(ugrt, s, "ref")
+    lcam = O.cam_from(setup.light_camera, setup.fovy, float(np.float32(W) / np.float32(H)))
+    F = r.F
+    for which in (ugrt.GRID_SPHERICAL, ugrt.GRID_UNIFORM):
+        def build():
+            if which == ugrt.GRID_SPHERICAL:
+                ctx.upload_camera(lcam.cc)
+                ctx.grid_build_spherical(r.d_faces, r.d_verts, F, float(np.float32(np.pi)), float(np.float32(np.pi)))
+            else:
+                ctx.grid_build_uniform(r.d_faces, r.d_verts, F, r.bbmin, r.bbmax)
+        parts = []
+        for k in range(nparts):
+            ctx.set_face_window(*parallel.face_window(k, nparts, F))
+            build()
+            value, key, span, offset, gi = ctx.grid_arrays(which)
+            parts.append((key.clone(), value.clone(), span.clone(), gi.total_refs))
+        ctx.grid_merge_shards(which, [p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts],
+                              [p[3] for p in parts])
+        ctx.synchronize()
+        value, key, span, offset, gi = ctx.grid_arrays(which)
+        got = [u32(x).copy() for x in (key, value, span, offset)] + [gi.total_refs, gi.cells_used]
+        ctx.set_face_window(0, 0)
+        build()
+        ctx.synchronize()
+        value, key, span, offset, gi = ctx.grid_arrays(which)
+        full = [u32(x) for x in (key, value, span, offset)] + [gi.total_refs, gi.cells_used]
+        for a, b in zip(got, full):
+            np.testing.assert_array_equal(a, b)
+        v3 = np.asarray(s["verts"], np.float32).reshape(-1, 3)
+        want = (O.grid_spherical(lcam.cc, s["faces"], s["verts"], *lg) if which == ugrt.GRID_SPHERICAL
+                else O.grid_uniform(s["faces"], s["verts"], v3.min(0), v3.max(0), udims))
+        np.testing.assert_array_equal(got[0], want["keys"])
+        np.testing.assert_array_equal(got[1], want["vals"])
+        np.testing.assert_array_equal(got[2], want["span"])
+        np.testing.assert_array_equal(got[3], want["offset"])
+        assert got[4] == want["R"] and got[5] == want["used"]

@@ -123,6 +123,9 @@ PROTOTYPES = {
     "ugrt_grid_build_uniform": (C.c_int, [_P, _P, _P, C.c_int, _F3, _F3]),
     "ugrt_grid_get_info": (C.c_int, [_P, C.c_int, C.POINTER(GridInfo)]),
     "ugrt_grid_get_slabs": (C.c_int, [_P, C.c_int, C.POINTER(SlabInfo)]),
+    "ugrt_ctx_set_face_window": (C.c_int, [_P, C.c_int, C.c_int]),
+    "ugrt_grid_merge_shards": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                         C.POINTER(C.c_uint)]),
     "ugrt_geometry_changed": (C.c_int, [_P]),
     "ugrt_sort_pairs": (C.c_int, [_P, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_int]),
     "ugrt_trace_primary": (C.c_int, [_P] * 11),

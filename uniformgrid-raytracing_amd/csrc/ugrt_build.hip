@@ -123,12 +123,14 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const
 							      const float *__restrict__ verts, int F, int lnbx,
 							      int lnby, float xM, float yM, Rng *__restrict__ rng,
 							      u32 *__restrict__ sizes, u32 *__restrict__ wide,
-							      u32 *__restrict__ wcount, float *__restrict__ projz)
+							      u32 *__restrict__ wcount, float *__restrict__ projz, int f_lo, int f_hi)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (f >= F)
 		f = F - 1;
+	// triangles outside [f_lo, f_hi) belong to another rank's shard of the build: no references here
 	const bool dup = (int)(blockIdx.x * BUILD_THREADS + threadIdx.x) >= F;
+	const bool outside = f < f_lo || f >= f_hi;
 	int blx[3], bly[3];
 	float rad[3];
 #pragma unroll
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_sph(CamBlock cam, const
 	r.x = (u32)gxmin | ((u32)gxmax << 16);
 	r.y = (u32)gymin | ((u32)gymax << 16);
 	r.z = 0;
-	u32 size = (u32)((gxmax - gxmin + 1) * (gymax - gymin + 1));
+	u32 size = outside ? 0u : (u32)((gxmax - gxmin + 1) * (gymax - gymin + 1));
 	size = d_split_wide(f, dup ? 0u : size, projz ? 0u : (u32)(lnbx * lnby), wide, wcount);
 	if (dup)
 		return;
@@ -289,12 +291,13 @@ __device__ __forceinline__ int d_ucell(const UGrid &g, int k, float p)
 __global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const int *__restrict__ faces,
 								  const float *__restrict__ verts, int F,
 								  Rng *__restrict__ rng, u32 *__restrict__ sizes,
-								  u32 *__restrict__ wide, u32 *__restrict__ wcount)
+								  u32 *__restrict__ wide, u32 *__restrict__ wcount, int f_lo, int f_hi)
 {
 	int f = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (f >= F)
 		f = F - 1;
 	const bool dup = (int)(blockIdx.x * BUILD_THREADS + threadIdx.x) >= F;
+	const bool outside = f < f_lo || f >= f_hi;
 	int i1 = 3 * faces[f * 3 + 0], i2 = 3 * faces[f * 3 + 1], i3 = 3 * faces[f * 3 + 2];
 	u32 packed[3], size = 1;
 #pragma unroll
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const 
 	r.x = packed[0];
 	r.y = packed[1];
 	r.z = packed[2];
-	size = d_split_wide(f, dup ? 0u : size, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], wide, wcount);
+	size = d_split_wide(f, (dup || outside) ? 0u : size, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], wide, wcount);
 	if (dup)
 		return;
 	rng[f] = r;
@@ -760,7 +763,7 @@ extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, c
 	hipLaunchKernelGGL(k_count_sph, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, lx, ly, xM, yM, (Rng *)G.rng.p,
 			   (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F),
-			   K > 1 ? (float *)G.projz.p : (float *)nullptr);
+			   K > 1 ? (float *)G.projz.p : (float *)nullptr, ctx->face_lo, ctx->face_hi > 0 ? ctx->face_hi : F);
 	UGRT_HIP(hipGetLastError());
 	if (K > 1 && (rc = build_slabs(ctx, G, F, 9999.9f, -9999.9f))) // frustum_grid.h:386
 		return rc;
@@ -800,11 +803,150 @@ extern "C" int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, con
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_uniform, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, g, d_facelist, d_vertlist, F, (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p,
-			   wide_counter(G, F));
+			   wide_counter(G, F), ctx->face_lo, ctx->face_hi > 0 ? ctx->face_hi : F);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
 	return build_common(ctx, G, F, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], g.dims[1], g.dims[2], 0,
 			    g.dims[1] - 1);
+}
+
+// ---------------------------------------------------------------------------
+// Sharded build: every rank builds the light / uniform grid for its window of the triangle
+// list (ugrt_ctx_set_face_window) and the ranks exchange their results.  A shard's lists are complete grid
+// arrays of its triangles: sorted by cell, ascending id inside a cell.  The windows are disjoint and ascending
+// with the rank, so the full build's run of a cell is the concatenation of the shards' runs in rank order:
+//   span[c] = sum_r span_r[c],  offset = exclusive scan,
+//   element i of shard r (cell c = key_r[i]) lands at offset[c] + sum_{r' < r} span_r'[c] + (i - offset_r[c]).
+// ---------------------------------------------------------------------------
+#define MERGE_MAX_PARTS 16
+struct MergeParts {
+	const u32 *keys[MERGE_MAX_PARTS], *vals[MERGE_MAX_PARTS], *span[MERGE_MAX_PARTS];
+	u32 count[MERGE_MAX_PARTS];
+	int n;
+};
+
+// total span per cell + the occupied cells; before[r][c] = sum of the spans of the parts before r
+__global__ __launch_bounds__(BUILD_THREADS) void k_shard_spans(MergeParts mp, u32 C, u32 *__restrict__ span,
+								u32 *__restrict__ before, u32 *__restrict__ used)
+{
+	u32 mine = 0;
+	for (u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x; c < C; c += gridDim.x * BUILD_THREADS) {
+		u32 acc = 0;
+		for (int r = 0; r < mp.n; r++) {
+			before[(size_t)r * C + c] = acc;
+			acc += mp.span[r][c];
+		}
+		span[c] = acc;
+		mine += acc != 0u ? 1u : 0u;
+	}
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		mine += (u32)__shfl_xor((int)mine, m);
+	if ((threadIdx.x & 63) == 0 && mine)
+		atomicAdd(used, mine);
+}
+
+// start of every cell's run inside part r (exclusive scan of span_r), written by the run heads of the part's keys
+__global__ __launch_bounds__(BUILD_THREADS) void k_shard_starts(const u32 *__restrict__ keys, u32 n,
+								 u32 *__restrict__ start)
+{
+	const u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (i >= n)
+		return;
+	const u32 k = keys[i];
+	if (i == 0 || keys[i - 1] != k)
+		start[k] = i;
+}
+
+__global__ __launch_bounds__(BUILD_THREADS) void k_shard_scatter(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
+								  u32 n, const u32 *__restrict__ start,
+								  const u32 *__restrict__ before, const u32 *__restrict__ offset,
+								  u32 *__restrict__ okeys, u32 *__restrict__ ovals)
+{
+	const u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (i >= n)
+		return;
+	const u32 c = keys[i];
+	const u32 pos = offset[c] + before[c] + (i - start[c]);
+	okeys[pos] = c;
+	ovals[pos] = vals[i];
+}
+
+extern "C" int ugrt_grid_merge_shards(ugrt_ctx *ctx, int which, int nparts, const unsigned *const *d_keys,
+				      const unsigned *const *d_vals, const unsigned *const *d_span,
+				      const unsigned *counts)
+{
+	if (!ctx || !d_keys || !d_vals || !d_span || !counts || nparts < 1 || nparts > MERGE_MAX_PARTS)
+		return ugrt_fail(UGRT_EINVAL, "grid_merge_shards: bad argument (1..%d parts)", MERGE_MAX_PARTS);
+	if (which != UGRT_GRID_SPHERICAL && which != UGRT_GRID_UNIFORM)
+		return ugrt_fail(UGRT_EINVAL, "grid_merge_shards: the light grid and the uniform grid are built in shards");
+	Grid &G = ctx->grid[which];
+	if (!G.valid)
+		return ugrt_fail(UGRT_EINVAL, "grid_merge_shards: build this rank's shard first (it defines the cells)");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	hipStream_t st = ctx->stream;
+	const u32 C = G.C;
+	MergeParts mp;
+	mp.n = nparts;
+	unsigned long long Rtot = 0;
+	for (int r = 0; r < nparts; r++) {
+		if (!d_span[r] || (counts[r] && (!d_keys[r] || !d_vals[r])))
+			return ugrt_fail(UGRT_EINVAL, "grid_merge_shards: null part %d", r);
+		mp.keys[r] = d_keys[r];
+		mp.vals[r] = d_vals[r];
+		mp.span[r] = d_span[r];
+		mp.count[r] = counts[r];
+		Rtot += counts[r];
+	}
+	if (Rtot > 0xFFFFFFF0ull)
+		return ugrt_fail(UGRT_ENOMEM, "grid_merge_shards: %llu references exceed the 32-bit lists", Rtot);
+	int rc;
+	// outputs: the context's grid arrays (the shard this context built is replaced; the parts are the caller's
+	// buffers and must not be these arrays)
+	const size_t rb = (size_t)(Rtot ? Rtot : 1) * 4;
+	if ((rc = ugrt_buf_reserve(ctx, G.key[0], rb)) || (rc = ugrt_buf_reserve(ctx, G.val[0], rb)) ||
+	    (rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 8 + 16)) || (rc = ugrt_buf_reserve(ctx, G.offset, (size_t)C * 4)) ||
+	    (rc = ugrt_buf_reserve(ctx, G.parts, (size_t)(nparts + 1) * C * 4)))
+		return rc;
+	for (int r = 0; r < nparts; r++)
+		if (d_keys[r] == (const unsigned *)G.key[0].p || d_vals[r] == (const unsigned *)G.val[0].p ||
+		    d_span[r] == (const unsigned *)G.span.p)
+			return ugrt_fail(UGRT_EINVAL, "grid_merge_shards: part %d aliases the context's own grid arrays", r);
+	u32 *span = (u32 *)G.span.p, *used = span + 2 * (size_t)C, *before = (u32 *)G.parts.p, *start = before + (size_t)nparts * C;
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
+	UGRT_HIP(hipMemsetAsync(used, 0, 4, st));
+	const u32 cblocks = (C + BUILD_THREADS - 1) / BUILD_THREADS;
+	hipLaunchKernelGGL(k_shard_spans, dim3(cblocks < 512u ? cblocks : 512u), dim3(BUILD_THREADS), 0, st, mp, C, span, before,
+			   used);
+	UGRT_HIP(hipGetLastError());
+	if ((rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)span, (u32 *)G.offset.p, (size_t)C)))
+		return rc;
+	for (int r = 0; r < nparts; r++) {
+		if (!counts[r])
+			continue;
+		const u32 n = counts[r];
+		hipLaunchKernelGGL(k_shard_starts, dim3((n + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   mp.keys[r], n, start);
+		hipLaunchKernelGGL(k_shard_scatter, dim3((n + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   mp.keys[r], mp.vals[r], n, (const u32 *)start, (const u32 *)(before + (size_t)r * C),
+				   (const u32 *)G.offset.p, (u32 *)G.key[0].p, (u32 *)G.val[0].p);
+		UGRT_HIP(hipGetLastError());
+	}
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + which, used, 4, hipMemcpyDeviceToHost, st));
+	G.keys = (u32 *)G.key[0].p;
+	G.vals = (u32 *)G.val[0].p;
+	G.R = (u32)Rtot;
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_ctx_set_face_window(ugrt_ctx *ctx, int begin, int end)
+{
+	if (!ctx || begin < 0 || end < begin)
+		return ugrt_fail(UGRT_EINVAL, "set_face_window: bad argument");
+	ctx->face_lo = begin;
+	ctx->face_hi = end; // 0 = up to the last triangle
+	return UGRT_OK;
 }
 
 extern "C" int ugrt_geometry_changed(ugrt_ctx *ctx)

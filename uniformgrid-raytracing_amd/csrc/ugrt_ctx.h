@@ -74,6 +74,7 @@ struct ugrt_ctx {
 	hipStream_t stream = nullptr;
 	CamBlock cam;
 	int nbx = 0, nby = 0; // screen grid
+	int face_lo = 0, face_hi = 0; // ugrt_ctx_set_face_window: triangles the light / uniform builds bin (hi 0 = all)
 	int p0 = 0, npix = 0; // first pixel and pixel count of this context's band
 	Grid grid[3];
 	DevBuf temp;                  // rocPRIM temporary storage

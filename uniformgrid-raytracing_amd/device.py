@@ -106,6 +106,17 @@ class Context:
         check(lib.ugrt_grid_get_info(self._h, which, C.byref(gi)))
         return gi
 
+    def set_face_window(self, begin, end):
+        """Triangles [begin, end) the light / uniform builds bin (0, 0 = all): this rank's shard of the build."""
+        check(lib.ugrt_ctx_set_face_window(self._h, int(begin), int(end)))
+
+    def grid_merge_shards(self, which, keys, vals, spans, counts):
+        """keys/vals/spans: per rank, device tensors (or pointers) of that rank's shard; counts: refs per rank."""
+        n = len(counts)
+        arr = lambda xs: (_P * n)(*[_ptr(x) for x in xs])
+        check(lib.ugrt_grid_merge_shards(self._h, which, n, arr(keys), arr(vals), arr(spans),
+                                         (C.c_uint * n)(*[int(c) for c in counts])))
+
     def grid_slabs(self, which):
         si = SlabInfo()
         check(lib.ugrt_grid_get_slabs(self._h, which, C.byref(si)))

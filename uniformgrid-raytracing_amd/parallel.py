@@ -73,3 +73,66 @@ class BandGather:
                 rb, _ = self.bands[r]
                 roff, rn = rb * 8 * self.width * 3, self.band_bytes(r)
                 image[roff:roff + rn].copy_(self.recv[r][:rn])
+
+
+def face_window(rank, world, num_faces):
+    """Triangles [begin, end) whose light / uniform grid references `rank` builds."""
+    return (rank * num_faces) // world, ((rank + 1) * num_faces) // world
+
+
+class GridShards:
+    """Exchange of the ranks' shards of a grid build: every rank ends up with every rank's (keys, values, span).
+
+    A shard is a complete set of grid arrays for the rank's window of the triangle list; the windows are disjoint
+    and ascending with the rank, so merging is concatenation per cell in rank order (ugrt_grid_merge_shards on the
+    device, merge_shards_numpy below as the same arithmetic on the host).  Three collectives per grid: the counts,
+    then keys and values padded to the largest shard, and the per-cell spans."""
+
+    def __init__(self, dist, torch, device, rank, world, host_staging=False):
+        self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.device = torch.device("cpu") if host_staging else device
+        self.out_device = device
+
+    def exchange(self, keys, vals, span, count):
+        """keys/vals: int32 tensors with >= count entries, span: int32 [C].  Returns lists over the ranks of
+        (keys, vals, span) tensors on the device plus the list of counts."""
+        t, dist = self.torch, self.dist
+        if self.world == 1:
+            return [keys[:count]], [vals[:count]], [span], [count]
+        cnt = t.tensor([count], dtype=t.int64, device=self.device)
+        counts = [t.zeros(1, dtype=t.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(counts, cnt)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        send = t.zeros(2 * cap, dtype=t.int32, device=self.device)
+        send[:count].copy_(keys[:count])
+        send[cap:cap + count].copy_(vals[:count])
+        recv = [t.zeros(2 * cap, dtype=t.int32, device=self.device) for _ in range(self.world)]
+        dist.all_gather(recv, send)
+        sp = span.to(self.device).contiguous()
+        spans = [t.zeros_like(sp) for _ in range(self.world)]
+        dist.all_gather(spans, sp)
+        dev = self.out_device
+        ks = [recv[r][:counts[r]].to(dev) for r in range(self.world)]
+        vs = [recv[r][cap:cap + counts[r]].to(dev) for r in range(self.world)]
+        return ks, vs, [x.to(dev) for x in spans], counts
+
+
+def merge_shards_numpy(keys, vals, spans):
+    """The merge of ugrt_grid_merge_shards on the host: (keys, vals, span, offset) of the full build."""
+    C = len(spans[0])
+    total = np.zeros(C, np.int64)
+    before = []
+    for sp in spans:
+        before.append(total.copy())
+        total += sp.astype(np.int64)
+    offset = np.concatenate([[0], np.cumsum(total)[:-1]])
+    R = int(total.sum())
+    okeys, ovals = np.zeros(R, np.uint32), np.zeros(R, np.uint32)
+    for r, (k, v, sp) in enumerate(zip(keys, vals, spans)):
+        k = np.asarray(k).astype(np.int64)
+        start = np.concatenate([[0], np.cumsum(sp.astype(np.int64))[:-1]])  # run starts inside the shard
+        pos = offset[k] + before[r][k] + (np.arange(len(k)) - start[k])
+        okeys[pos] = k
+        ovals[pos] = np.asarray(v).astype(np.uint32)
+    return okeys, ovals, total.astype(np.uint32), offset.astype(np.uint32)

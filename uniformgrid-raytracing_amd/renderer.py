@@ -43,7 +43,8 @@ def make_camera(params, fovy, aspect):
 
 
 class Renderer:
-    def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False):
+    def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False,
+                 shards=None):
         """overlap=True: the light grid and the uniform grid (which do not depend on the camera pass) are built
         by a second context on a second HIP stream while the main stream builds the perspective grid and
         traces the primary rays; streams are joined with events before the grids are consumed.  Same results.
@@ -53,6 +54,10 @@ class Renderer:
         self.ctx = ctx
         self.aux = None
         self._worker = None
+        # parallel.GridShards: the light grid and the uniform grid are built in shards of the triangle list, one
+        # per rank, exchanged and merged; one-stream frames only
+        self.shards = shards
+        assert not (overlap and shards is not None), "sharded builds run in the one-stream frame"
         if overlap:
             from .device import Context
 
@@ -171,7 +176,11 @@ class Renderer:
             lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
             ctx.upload_camera(lcam.camcoords)
             ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
-            ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
+            if self.shards is not None:
+                self._sharded(GRID_SPHERICAL,
+                              lambda: ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F))
+            else:
+                ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
             lvalue, lspan, loffset, _ = ctx.grid_ptrs(GRID_SPHERICAL)
             self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
             ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
@@ -183,7 +192,11 @@ class Renderer:
             ctx.reflect_rays(self.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
                              self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays,
                              self.active)
-            ctx.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
+            if self.shards is not None:
+                self._sharded(GRID_UNIFORM, lambda: ctx.grid_build_uniform(self.d_faces, self.d_verts, self.F,
+                                                                            self.bbmin, self.bbmax))
+            else:
+                ctx.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
             uvalue, uspan, uoffset, _ = ctx.grid_ptrs(GRID_UNIFORM)
             ctx.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active, self.hit_t,
                           self.hit_id)
@@ -275,6 +288,21 @@ class Renderer:
                                 self.d_matidx, self.d_matlist, self.num_materials)
         if shadows:
             ctx.shade_add_shadows(self.image, self.is_shadowed)
+
+    def _sharded(self, which, build):
+        """Runs `build` on this rank's window of the triangle list, exchanges the shards, merges them."""
+        from .parallel import face_window
+
+        ctx, sh = self.ctx, self.shards
+        ctx.set_face_window(*face_window(sh.rank, sh.world, self.F))
+        build()
+        value, key, span, offset, gi = ctx.grid_arrays(which)
+        ks, vs, sps, counts = sh.exchange(key, value, span, gi.total_refs)
+        if sh.world == 1:  # the parts must not be the context's own arrays
+            ks, vs, sps = [ks[0].clone()], [vs[0].clone()], [sps[0].clone()]
+        ctx.grid_merge_shards(which, ks, vs, sps, counts)
+        self._shard_parts = (ks, vs, sps)  # alive until the merge has run
+        ctx.set_face_window(0, 0)
 
     def synchronize(self):
         self.ctx.synchronize()

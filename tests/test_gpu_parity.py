@@ -807,3 +807,101 @@ def test_sharded_grid_build_merge(ugrt, O, torch, name, nparts):
         np.testing.assert_array_equal(got[2], want["span"])
         np.testing.assert_array_equal(got[3], want["offset"])
         assert got[4] == want["R"] and got[5] == want["used"]
+
+
+def test_full_size_hall_1024(ugrt, O, torch):
+    """BASELINE configs[1] at full size: the ~80 k-triangle hall at the reference's own 1024 x 1024 and
+    128 x 128 light cells (main.cu.h:10-26), primary + shadow.  1024 is the one width at which the exact bilinear
+    fetch of the direction table has the k/256 weights of the hardware filter (ray set-up).  The
+    reference's launch rule (strict) is checked against the oracle on the WHOLE frame - which chunks are traced
+    depends on all rays - and the all-chunks mode on a band of tile rows."""
+    s = ugrt.scenes.hall(scale=1.0)
+    W = H = 1024
+    lg = (128, 128)
+    setup = setup_for(ugrt, s, "ref")
+    assert 70000 < s["num_faces"] < 90000
+    # strict launch rule, whole frame
+    ctx, r = make(ugrt, s, W, H, lg)
+    r.display(setup, frame_cnt=1, shadows=True)
+    ctx.synchronize()
+    want = O.frame(s, setup, W, H, light_grid=lg, all_chunks=False)
+    pr = want["primary"]
+    np.testing.assert_array_equal(r.t.cpu().numpy().view(np.uint32), bits(pr["t"]))
+    assert_bits_equal(r.dir.cpu().numpy(), pr["dir"], "dir")
+    assert_bits_equal(r.normal.cpu().numpy(), pr["normal"], "normal")
+    for which, key in ((ugrt.GRID_PERSPECTIVE, "grid"), (ugrt.GRID_SPHERICAL, "lgrid")):
+        value, keys, span, offset, gi = ctx.grid_arrays(which)
+        assert gi.num_cells == 16384 and gi.total_refs == want[key]["R"]
+        np.testing.assert_array_equal(u32(keys), want[key]["keys"])
+        np.testing.assert_array_equal(u32(value), want[key]["vals"])
+        np.testing.assert_array_equal(u32(span), want[key]["span"])
+        np.testing.assert_array_equal(u32(offset), want[key]["offset"])
+    np.testing.assert_array_equal(u32(r.d_map), want["map"])
+    assert r.num_chunks == want["nchunks"]
+    np.testing.assert_array_equal(u32(r.prefix)[:r.num_chunks], want["prefix"][:want["nchunks"]])
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"])
+    np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"])
+    np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
+    assert (pr["id"] >= 0).mean() > 0.5 and want["is_shadowed"].sum() > 1000
+    # all chunks, a band of tile rows (a ray's flag does not depend on the other rays then)
+    ctx2, r2 = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS)
+    r2.display(setup, frame_cnt=1, shadows=True)
+    ctx2.synchronize()
+    rows = (60, 68)
+    wb = O.frame(s, setup, W, H, rows=rows, light_grid=lg, all_chunks=True)
+    a, b = wb["p0"], wb["p0"] + wb["n"]
+    np.testing.assert_array_equal(r2.is_shadowed.cpu().numpy()[a:b], wb["is_shadowed"][a:b])
+    np.testing.assert_array_equal(r2.image.cpu().numpy()[3 * a:3 * b], wb["image"][3 * a:3 * b])
+    # every ray of the strict frame that is shadowed is shadowed with all chunks traced
+    assert (r2.is_shadowed.cpu().numpy() >= want["is_shadowed"]).all()
+
+
+def test_full_size_animated_rebuild(ugrt, O, torch):
+    """BASELINE configs[4] at full size: the 1 M-triangle scene at 1920 x 1080, the 800 k-triangle sub-range
+    transformed by Model::rotate_bunny(1.81 + 0.05 k) (scene.h:122, transformation_kernel.cu:4-18) before each of
+    three frames, all grids rebuilt from the moved vertices.  Vertices bit-equal to the oracle's; the last frame
+    against the oracle on a band of tile rows plus the whole-frame properties."""
+    import ctypes
+
+    s = ugrt.scenes.crash(scale=1.0)
+    W, H, lg, ud = 1920, 1080, (128, 128), (128, 128, 64)
+    setup = setup_for(ugrt, s, "ref")
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY  # as bench.py --animate runs it
+    ctx, r = make(ugrt, s, W, H, lg, flags=flags, udims=ud)
+    off, size = s["animated_offset"], s["animated_size"]
+    assert size >= 700000
+    r.init_orig_list(size, off)
+    verts = np.ascontiguousarray(s["verts"], np.float32).reshape(-1).copy()
+    orig = verts[3 * off:3 * (off + size)].copy()
+    for k in range(3):
+        rot = 1.81 + 0.05 * k
+        r.rotate_bunny(rot)
+        r.display(setup, shadows=True, reflect=True)
+        cr, sr = ctypes.c_float(), ctypes.c_float()
+        ugrt.lib.ugrt_rot_cos_sin(rot, ctypes.byref(cr), ctypes.byref(sr))
+        O.animate(verts, orig, size, off, cr.value, sr.value)
+    ctx.synchronize()
+    assert_bits_equal(r.d_verts.cpu().numpy(), verts, "animated vertices")
+    N = W * H
+    for which in (ugrt.GRID_PERSPECTIVE, ugrt.GRID_SPHERICAL, ugrt.GRID_UNIFORM):
+        value, key, span, offset, gi = ctx.grid_arrays(which)
+        k_, v_ = u32(key).astype(np.int64), u32(value).astype(np.int64)
+        assert (np.diff(k_) >= 0).all() and gi.total_refs == len(k_)
+        same = k_[1:] == k_[:-1]
+        assert (v_[1:][same] > v_[:-1][same]).all()
+        np.testing.assert_array_equal(np.bincount(k_, minlength=gi.num_cells), u32(span).astype(np.int64))
+    dm = u32(r.d_map)
+    assert (np.sort(dm[:N]) == np.arange(N)).all() and (np.diff(dm[N:].astype(np.int64)) >= 0).all()
+    rows = (64, 68)
+    want = O.frame(s, setup, W, H, rows=rows, light_grid=lg, all_chunks=True, reflect=True, uniform_dims=ud, verts=verts)
+    a, b = want["p0"], want["p0"] + want["n"]
+    np.testing.assert_array_equal(r.t.cpu().numpy()[a:b].view(np.uint32), want["primary"]["t"][a:b].view(np.uint32))
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy()[a:b], want["is_shadowed"][a:b])
+    np.testing.assert_array_equal(r.hit_id.cpu().numpy()[a:b], want["hit_id"][a:b])
+    np.testing.assert_array_equal(r.hit_t.cpu().numpy()[a:b].view(np.uint32), want["hit_t"][a:b].view(np.uint32))
+    np.testing.assert_array_equal(r.image.cpu().numpy()[3 * a:3 * b], want["image"][3 * a:3 * b])
+    # the moved geometry is what was traced: the static frame differs from this one
+    ctx0, r0 = make(ugrt, s, W, H, lg, flags=flags, udims=ud)
+    r0.display(setup, shadows=True, reflect=True)
+    ctx0.synchronize()
+    assert (r0.image.cpu().numpy()[3 * a:3 * b] != want["image"][3 * a:3 * b]).any()

@@ -1,0 +1,286 @@
+// display_main.cpp -- the reference's frame loop (display(), main.cu:59-302) as a C++ host program over libugrt.so.
+//
+// What a maintainer of the reference ends up with after swapping the class bodies for integration/ugrt_shim.h:
+// display() keeps its order - updateLightPosition, camera, fillCoordinatesData, build_frustum_grid, trace, per light
+// { light camera, fillCoordinatesData, getEffectiveRayGridMapping, build_secondary_frustum_grid, processData,
+// check_for_shadows }, simpleShade | spotlight_shade, add_shadows, writePPM.  GLUT, the PBO and the ImageMagick shell
+// calls are gone; resolution and cameras come from a parameter file instead of main.cu.h / the source text.
+// `streams 2` runs the same frame on two contexts and two HIP streams from this ONE host thread (light grid on the
+// side stream beside the camera pass), `reflect 1` adds the bounce (uniform grid + 3D-DDA).
+//
+//   display_main PARAMS OUT.ppm        PARAMS: lines "key v0 v1 ..." (see read_params)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static int g_width = 1024, g_height = 1024; // main.cu.h:10-11
+#define SCREEN_WIDTH g_width
+#define SCREEN_HEIGHT g_height
+#define FOVY 45.0f // main.cu.h:14
+#define PREFIX_CAPACITY ((unsigned)(g_width * g_height / 64 + 128 * 128 + 2))
+#include "ugrt_shim.h"
+
+#define HIP_CHECK(call)                                                              \
+	do {                                                                         \
+		hipError_t e_ = (call);                                              \
+		if (e_ != hipSuccess) {                                              \
+			fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); \
+			exit(-1);                                                    \
+		}                                                                    \
+	} while (0)
+
+Model *model;
+Camera *camera;
+FrustumGrid *fGrid;
+FrustumTracer *fTracer;
+DecisionData *dData;
+Shader *shader;
+unsigned char *h_image, *d_image;
+float h_light_position[3] = { 10.0f, 12.0f, 6.0f }; // per_frame_funcs.h:8-10
+int frame_cnt = 0;
+
+struct Params {
+	char obj[512], mat[512];
+	float cam[11], light[11]; // eye, look, up, near, far
+	int streams, reflect, frames, animate_size, animate_offset;
+	unsigned flags;
+} P;
+
+static void read_params(const char *path)
+{
+	FILE *fp = fopen(path, "r");
+	if (!fp) {
+		perror(path);
+		exit(1);
+	}
+	char key[64];
+	P.streams = 1, P.frames = 1;
+	while (fscanf(fp, "%63s", key) == 1) {
+		if (!strcmp(key, "obj"))
+			(void)!fscanf(fp, "%511s", P.obj);
+		else if (!strcmp(key, "mat"))
+			(void)!fscanf(fp, "%511s", P.mat);
+		else if (!strcmp(key, "size"))
+			(void)!fscanf(fp, "%d %d", &g_width, &g_height);
+		else if (!strcmp(key, "camera"))
+			for (int i = 0; i < 11; i++)
+				(void)!fscanf(fp, "%f", &P.cam[i]);
+		else if (!strcmp(key, "light_camera"))
+			for (int i = 0; i < 11; i++)
+				(void)!fscanf(fp, "%f", &P.light[i]);
+		else if (!strcmp(key, "shading_light"))
+			(void)!fscanf(fp, "%f %f %f", &h_light_position[0], &h_light_position[1], &h_light_position[2]);
+		else if (!strcmp(key, "streams"))
+			(void)!fscanf(fp, "%d", &P.streams);
+		else if (!strcmp(key, "reflect"))
+			(void)!fscanf(fp, "%d", &P.reflect);
+		else if (!strcmp(key, "frames"))
+			(void)!fscanf(fp, "%d", &P.frames);
+		else if (!strcmp(key, "flags"))
+			(void)!fscanf(fp, "%u", &P.flags);
+		else {
+			fprintf(stderr, "unknown key %s\n", key);
+			exit(1);
+		}
+	}
+	fclose(fp);
+}
+
+template <typename T>
+static T *dev_alloc(size_t n)
+{
+	T *p = nullptr;
+	HIP_CHECK(hipMalloc((void **)&p, (n ? n : 1) * sizeof(T)));
+	return p;
+}
+template <typename T>
+static T *dev_copy(const T *h, size_t n)
+{
+	T *p = dev_alloc<T>(n);
+	HIP_CHECK(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
+	return p;
+}
+
+void Model::upload() // scene.h:326-328
+{
+	d_vertexlist = dev_copy(ugrt_scene_vertexlist(s), (size_t)3 * num_vertices);
+	d_facelist = dev_copy(ugrt_scene_facelist(s), (size_t)3 * num_faces);
+	d_materiallist_index = dev_copy(ugrt_scene_materiallist_index(s), (size_t)num_faces);
+	d_materiallist = dev_copy(ugrt_scene_materiallist(s), (size_t)6 * num_materials);
+}
+
+static void set_camera(const float *c)
+{
+	camera->setCameraCenter(c[0], c[1], c[2]);
+	camera->setCameraLookAt(c[3], c[4], c[5]);
+	camera->setCameraUp(c[6], c[7], c[8]);
+	camera->setNearFar(c[9], c[10]);
+	camera->adjustCameraAndPosition();
+	camera->getGLMatrices();
+	camera->getFrustumProperties();
+}
+
+// the bounce and the second stream are not in the reference: their state lives here
+static ugrt_ctx *g_aux;
+static hipStream_t g_main, g_side;
+static hipEvent_t ev_geometry, ev_primary, ev_light_grid, ev_side_done;
+static float *d_reflect, *d_rays, *d_hit_t;
+static int *d_active, *d_hit_id;
+
+void display() // main.cu:59-302
+{
+	frame_cnt++;
+	const bool two = P.streams == 2;
+	updateLightPosition();
+	set_camera(P.cam); // main.cu:87-126
+	HIP_CHECK(hipMemcpyAsync(camera->d_cam_position, camera->worldori, sizeof(float) * 3, hipMemcpyHostToDevice, g_main)); // :128
+	fillCoordinatesData();
+	ugrt_camera light_cam;
+	{ // the light's camera block is needed early by the side stream; display() itself sets it up below (main.cu:158-170)
+		Camera lc;
+		lc.setCameraCenter(P.light[0], P.light[1], P.light[2]);
+		lc.setCameraLookAt(P.light[3], P.light[4], P.light[5]);
+		lc.setCameraUp(P.light[6], P.light[7], P.light[8]);
+		lc.setNearFar(P.light[9], P.light[10]);
+		lc.adjustCameraAndPosition();
+		light_cam = lc.cam;
+	}
+	float bbmin[3] = { model->xMin, model->yMin, model->zMin }, bbmax[3] = { model->xMax, model->yMax, model->zMax };
+	FrustumGrid lightGrid(0), uniGrid(0);
+	if (two) { // side stream: the grids that only depend on the geometry, beside the camera pass
+		HIP_CHECK(hipEventRecord(ev_geometry, g_main));
+		HIP_CHECK(hipStreamWaitEvent(g_side, ev_geometry, 0));
+		UGRT_CHECK(ugrt_upload_camera(g_aux, light_cam.camcoords));
+		UGRT_CHECK(ugrt_grid_build_spherical(g_aux, model->d_facelist, model->d_vertexlist, model->num_faces, (float)M_PI,
+						     (float)M_PI));
+		HIP_CHECK(hipEventRecord(ev_light_grid, g_side));
+		lightGrid.fetch(g_aux, UGRT_GRID_SPHERICAL);
+		if (P.reflect) {
+			UGRT_CHECK(ugrt_grid_build_uniform(g_aux, model->d_facelist, model->d_vertexlist, model->num_faces, bbmin, bbmax));
+			uniGrid.fetch(g_aux, UGRT_GRID_UNIFORM);
+		}
+	}
+	fGrid->buildGrid(model->d_facelist, model->d_vertexlist); // build_frustum_grid, main.cu:133
+	fTracer->trace(fGrid->d_triangle_value_list, fGrid->d_span, fGrid->d_offset, dData->d_primary_ray_normal,
+		       dData->d_primary_ray_t_value, dData->d_primary_ray_direction, dData->d_is_shadowed, dData->d_intersect_id,
+		       model->d_vertexlist, model->d_facelist); // main.cu:141
+	if (two && P.reflect) { // the bounce only needs the primary hits
+		HIP_CHECK(hipEventRecord(ev_primary, g_main));
+		HIP_CHECK(hipStreamWaitEvent(g_side, ev_primary, 0));
+		UGRT_CHECK(ugrt_reflect_rays(g_aux, camera->d_cam_position, dData->d_primary_ray_t_value, dData->d_primary_ray_direction,
+					     dData->d_intersect_id, model->d_materiallist_index, d_reflect, model->num_materials,
+					     model->d_vertexlist, model->d_facelist, 1e-3f, d_rays, d_active));
+		UGRT_CHECK(ugrt_trace_dda(g_aux, uniGrid.d_triangle_value_list, uniGrid.d_span, uniGrid.d_offset, model->d_vertexlist,
+					  model->d_facelist, d_rays, d_active, d_hit_t, d_hit_id));
+	}
+	if (two)
+		HIP_CHECK(hipEventRecord(ev_side_done, g_side));
+	for (int l = 0; l < 1; l++) { // h_numLights = 1, main.cu.h:40
+		set_camera(P.light); // main.cu:158-168
+		fillCoordinatesData();
+		// getRayGridMapping + the host max loop (main.cu:172-185) only feed values that :186-187 overwrite
+		const float x_max = (float)M_PI, y_max = (float)M_PI;
+		getEffectiveRayGridMapping(dData->d_primary_ray_t_value, dData->d_primary_ray_direction, dData->d_map,
+					   camera->d_cam_position, x_max, y_max);
+		if (two) {
+			HIP_CHECK(hipStreamWaitEvent(g_main, ev_light_grid, 0));
+			*fGrid = lightGrid;
+		} else {
+			fGrid->buildSphericalGrid(model->d_facelist, model->d_vertexlist, x_max, y_max); // build_secondary_frustum_grid
+		}
+		processData();
+		check_for_shadows(l);
+	}
+	if (two)
+		HIP_CHECK(hipStreamWaitEvent(g_main, ev_side_done, 0));
+	if (P.reflect) {
+		if (!two) {
+			UGRT_CHECK(ugrt_reflect_rays(g_ctx, camera->d_cam_position, dData->d_primary_ray_t_value,
+						     dData->d_primary_ray_direction, dData->d_intersect_id, model->d_materiallist_index,
+						     d_reflect, model->num_materials, model->d_vertexlist, model->d_facelist, 1e-3f, d_rays,
+						     d_active));
+			UGRT_CHECK(ugrt_grid_build_uniform(g_ctx, model->d_facelist, model->d_vertexlist, model->num_faces, bbmin, bbmax));
+			uniGrid.fetch(g_ctx, UGRT_GRID_UNIFORM);
+			UGRT_CHECK(ugrt_trace_dda(g_ctx, uniGrid.d_triangle_value_list, uniGrid.d_span, uniGrid.d_offset,
+						  model->d_vertexlist, model->d_facelist, d_rays, d_active, d_hit_t, d_hit_id));
+		}
+		UGRT_CHECK(ugrt_shade_reflect(g_ctx, d_image, dData->d_primary_ray_normal, dData->d_primary_ray_t_value,
+					      dData->d_primary_ray_direction, dData->d_intersect_id, camera->d_cam_position,
+					      model->d_materiallist_index, model->d_materiallist, d_reflect, model->num_materials,
+					      model->d_vertexlist, model->d_facelist, d_rays, d_active, d_hit_t, d_hit_id));
+	} else if (frame_cnt < 2) { // main.cu:205-219
+		shader->simpleShade(d_image, dData->d_primary_ray_normal, dData->d_primary_ray_t_value, dData->d_primary_ray_direction,
+				    dData->d_intersect_id, camera->d_cam_position, model->d_materiallist_index, model->d_materiallist,
+				    model->num_materials);
+	} else {
+		shader->spotlight_shade(d_image, dData->d_primary_ray_normal, dData->d_primary_ray_t_value,
+					dData->d_primary_ray_direction, dData->d_intersect_id, camera->d_cam_position,
+					model->d_materiallist_index, model->d_materiallist, model->num_materials);
+	}
+	shader->add_shadows(d_image, dData->d_is_shadowed); // main.cu:223
+}
+
+int main(int argc, char **argv)
+{
+	if (argc != 3) {
+		fprintf(stderr, "usage: %s PARAMS OUT.ppm\n", argv[0]);
+		return 2;
+	}
+	read_params(argv[1]);
+	const size_t N = (size_t)g_width * g_height;
+	HIP_CHECK(hipSetDevice(0));
+	HIP_CHECK(hipStreamCreate(&g_main));
+	init_ugrt(g_width, g_height, P.flags);
+	UGRT_CHECK(ugrt_ctx_set_stream(g_ctx, g_main));
+	if (P.streams == 2) {
+		ugrt_config cfg = { g_width, g_height, 8, 1, 128, 128, 0, g_height / 8, P.flags, { 128, 128, 64 } };
+		UGRT_CHECK(ugrt_ctx_create(&g_aux, 0, &cfg));
+		HIP_CHECK(hipStreamCreate(&g_side));
+		UGRT_CHECK(ugrt_ctx_set_stream(g_aux, g_side));
+		HIP_CHECK(hipEventCreateWithFlags(&ev_geometry, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ev_primary, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ev_light_grid, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ev_side_done, hipEventDisableTiming));
+	}
+	model = new Model(1); // initData(), main.cu:304-329
+	model->some_material(P.mat);
+	model->load_model(P.obj);
+	camera = new Camera();
+	camera->d_cam_position = dev_alloc<float>(3);
+	fGrid = new FrustumGrid(0);
+	fTracer = new FrustumTracer();
+	shader = new Shader();
+	dData = new DecisionData(); // decision_data.h:64-78
+	dData->d_primary_ray_normal = dev_alloc<float>(3 * N);
+	dData->d_primary_ray_t_value = dev_alloc<float>(N);
+	dData->d_primary_ray_direction = dev_alloc<float>(3 * N);
+	dData->d_is_shadowed = dev_alloc<int>(N);
+	dData->d_intersect_id = dev_alloc<int>(N);
+	dData->d_map = dev_alloc<unsigned>(2 * N);
+	dData->d_prefixMap = dev_alloc<unsigned>(PREFIX_CAPACITY);
+	dData->h_numCudaBlocks = new size_t(0);
+	d_image = dev_alloc<unsigned char>(3 * N);
+	h_image = (unsigned char *)malloc(3 * N);
+	if (P.reflect) {
+		int nm = 0;
+		const float *refl = ugrt_scene_reflectlist(model->scene(), &nm);
+		std::vector<float> r((size_t)model->num_materials, 0.0f);
+		for (int i = 0; i < nm && i < model->num_materials; i++)
+			r[i] = refl[i];
+		d_reflect = dev_copy(r.data(), r.size());
+		d_rays = dev_alloc<float>(6 * N);
+		d_active = dev_alloc<int>(N);
+		d_hit_t = dev_alloc<float>(N);
+		d_hit_id = dev_alloc<int>(N);
+	}
+	for (int f = 0; f < P.frames; f++)
+		display();
+	HIP_CHECK(hipMemcpyAsync(h_image, d_image, 3 * N, hipMemcpyDeviceToHost, g_main)); // main.cu:244
+	HIP_CHECK(hipStreamSynchronize(g_main));
+	writePPM(argv[2]);
+	printf("frames %d streams %d chunks %zu\n", frame_cnt, P.streams, *dData->h_numCudaBlocks);
+	return 0;
+}

@@ -1,26 +1,3 @@
-# INTEGRATION — using `libugrt.so` from the reference's host code
-
-The reference (`/root/reference`) is one nvcc translation unit: `main.cu` includes the host "classes"
-(`scene.h`, `camera.h`, `frustum_grid.h`, `frustum_tracer.h`, `decision_data.h`, `shader.h`), which include the `.cu`
-kernel files. It has no FFI. The drop-in boundary is therefore the set of C++ methods `display()` calls
-(`main.cu:59-302`); `include/ugrt.h` exports one C function per method with the same argument order. A maintainer
-keeps `main.cu`'s frame loop and replaces the class bodies with the stubs below; the `.cu` includes, the CUDPP plans
-and every `cudaMalloc` of grid lists go away.
-
-Build: `make -C uniformgrid-raytracing_amd/csrc` → `uniformgrid-raytracing_amd/libugrt.so` (hipcc, gfx950).
-Link the host program with `-L… -lugrt` (plain C ABI, no C++ types cross the boundary). Device pointers are HIP
-pointers (`hipMalloc`); the context's stream is set with `ugrt_ctx_set_stream`.
-
-## C++ binding stubs (what replaces the reference's class bodies)
-
-The block below is `integration/ugrt_shim.h`, verbatim (`tests/test_native_driver.py` compares the two), and it is
-compiled: `integration/display_main.cpp` is `display()` of `main.cu:59-302` written against these classes — a C++
-host program with no Python in the process, built by `make -C integration` (and by `__graft_entry__.build()`). On the
-GPU box `tests/test_native_driver.py::test_cpp_display_writes_the_oracle_image` runs it on a generated `.obj` +
-material file, in the one-stream and the two-stream form, with and without the bounce, and compares the PPM it
-writes with the oracle's frame.
-
-```cpp
 // ugrt_shim.h -- drop-in replacements for the reference's host classes (same names, same method signatures),
 // every body one call into libugrt.so.  The including program defines, before the #include, what main.cu.h
 // defines - SCREEN_WIDTH, SCREEN_HEIGHT, FOVY - and PREFIX_CAPACITY >= SCREEN_WIDTH*SCREEN_HEIGHT/64 + 128*128 + 2,
@@ -199,42 +176,3 @@ static void writePPM(char *f) // per_app_funcs.h:39
 	}
 }
 #endif
-```
-
-Two optional entries have no class to stand in for. `ugrt_sort_pairs` is the CUDPP call the reference makes itself
-(`cudppSort`, `frustum_grid.h:298`, `decision_data.h:177`): a maintainer who keeps a stage of his own can sort with
-it. `UGRT_FLAG_STATIC_GEOMETRY` in `ugrt_config.flags` + `ugrt_geometry_changed(g_ctx)` after every
-`cudaMemcpy` into `d_vertexlist` (`Model::tmp_model`'s per-frame upload, `scene.h:70-119`) lets the three builds of
-a frame share one set of triangle records; `rotate_bunny` → `ugrt_animate` invalidates them by itself. Without the
-flag nothing has to be called and every build assumes new geometry.
-
-`display()` then runs unchanged in its reference order (`main.cu:134-223`). Things the maintainer deletes:
-`getRayGridMapping` + the two D2H copies and host max loop (`main.cu:172-185`, results overwritten by `:186-187`),
-all `cudppPlan`s, `cudaThreadSynchronize()` pairs, the 1 M-line `printf` in `Shader::spotlight_shade` (`shader.h:108-112`).
-
-## Two streams
-
-`display()` can keep its order and still use the chip better: give the light-grid build, the uniform-grid build and
-the bounce a second `ugrt_ctx` on its own stream (`ugrt_ctx_set_stream`). `integration/display_main.cpp` (`streams 2`)
-does it from its one host thread; a build blocks its caller once while it reads `total_refs` back, so a host that wants
-both streams busy all the time calls the second context from a second thread (what `renderer.py` does). Join with events: `hipEventRecord` behind
-`ugrt_trace_primary` → `hipStreamWaitEvent` on the side stream before `ugrt_reflect_rays`; an event behind
-`ugrt_grid_build_spherical` → the main stream waits for it before `ugrt_trace_shadow` (which takes that grid's arrays
-from the second context's `ugrt_grid_get_info`); the main stream waits for the side stream before `ugrt_shade_reflect`.
-`uniformgrid-raytracing_amd/renderer.py::_display_overlapped` is that sequence (2.53 → 2.15 ms per frame on the bench
-scene).
-
-## ctypes binding (what the tests and `bench.py` use)
-
-`uniformgrid-raytracing_amd/__init__.py` holds a `PROTOTYPES` table with `restype/argtypes` for every symbol of
-`include/ugrt.h` (`tests/test_abi.py` checks the table against the header and the built library). Device buffers are
-torch tensors; only `tensor.data_ptr()` crosses the boundary. Import torch **before** loading `libugrt.so` in a
-process that uses both: PyTorch-ROCm bundles its own `libamdhip64.so.7`, and device pointers are only valid inside one
-HIP runtime (the package does this for you).
-
-## Multi-GPU
-
-One process per GPU. Give each process a context for its band of tile rows
-(`ugrt_config.row_begin/row_end = parallel.band_rows(rank, world, H/8)`); every rank loads the whole scene; after
-`ugrt_shade_*` gather `image[3·W·8·row_begin : 3·W·8·row_end]` to rank 0 (`ncclGather`/`torch.distributed.gather`,
-RCCL over xGMI). No other communication.

@@ -1,0 +1,79 @@
+"""The reference-side binding, compiled: integration/ugrt_shim.h (the class stubs INTEGRATION.md shows) and
+integration/display_main.cpp (display() of main.cu:59-302 in C++ over the C-ABI, one- and two-stream)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INTEG = os.path.join(ROOT, "integration")
+BIN = os.path.join(INTEG, "display_main")
+
+
+def _build():
+    subprocess.run(["make", "-C", INTEG], check=True, capture_output=True)
+    assert os.path.exists(BIN)
+
+
+def test_shim_compiles_against_the_header():
+    """hipcc builds the driver (ugrt.h + the shim + the frame loop) and links it to libugrt.so; no GPU needed."""
+    _build()
+    out = subprocess.run(["ldd", BIN], capture_output=True, text=True).stdout
+    assert "libugrt.so" in out and "oracle" not in out
+
+
+def test_integration_md_quotes_the_shim_verbatim():
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = open(os.path.join(INTEG, "ugrt_shim.h")).read()
+    blocks = re.findall(r"```cpp\n(.*?)```", md, re.S)
+    assert any(b == shim for b in blocks), "INTEGRATION.md must contain integration/ugrt_shim.h as a cpp block"
+
+
+def _read_ppm(path):
+    tok = open(path).read().split()
+    assert tok[0] == "P3" and tok[3] == "255"
+    w, h = int(tok[1]), int(tok[2])
+    return np.array(tok[4:], dtype=np.int64).astype(np.uint8).reshape(h * w * 3), w, h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams,reflect,all_chunks", [(1, 0, 0), (2, 0, 1), (1, 1, 1), (2, 1, 1)])
+def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect, all_chunks):
+    """A C++ host (no Python, no torch in the process) loads the OBJ + material file, runs display() through the
+    shim classes and writes the PPM; the pixels are the oracle's frame."""
+    _build()
+    d = str(tmp_path)
+    s = ugrt.scenes.hall(d, scale=0.1) if not reflect else ugrt.scenes.crash(d, scale=0.02)
+    W, H = 256, 256
+    cam, lcam = s["cameras"]["ref"], s["light_camera"]
+    flat = lambda c: " ".join("%.9g" % v for v in (list(c["eye"]) + list(c["look"]) + list(c["up"]) + [c["near"], c["far"]]))
+    params = os.path.join(d, "params.txt")
+    with open(params, "w") as f:
+        f.write("obj %s\nmat %s\nsize %d %d\ncamera %s\nlight_camera %s\nshading_light %s\nstreams %d\nreflect %d\n"
+                "frames 2\nflags %d\n" % (s["obj"], s["mat"], W, H, flat(cam), flat(lcam),
+                                        " ".join("%.9g" % v for v in s["shading_light"]), streams, reflect,
+                                        ugrt.FLAG_SHADOW_ALL_CHUNKS if all_chunks else 0))
+    out = os.path.join(d, "out.ppm")
+    # the mtllib is opened relative to the cwd (obj_parser.cpp:417)
+    p = subprocess.run([BIN, params, out], cwd=d, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got, w, h = _read_ppm(out)
+    assert (w, h) == (W, H)
+    m = ugrt.Model()
+    m.some_material(s["mat"])
+    cwd = os.getcwd()
+    os.chdir(d)
+    try:
+        m.load_model(s["obj"])
+    finally:
+        os.chdir(cwd)
+    sc = dict(s, verts=m.h_vertexlist.reshape(-1, 3), faces=m.h_facelist.reshape(-1, 3), matidx=m.h_materiallist_index,
+              mat_list=m.h_materiallist.reshape(-1, 6), reflect=m.h_reflectlist)
+    setup = ugrt.FrameSetup(cam, lcam, s["shading_light"])
+    # frame 2 of the loop: spot shading without the bounce (main.cu:205-219, Q19); the bounce shades as frame 1
+    want = O.frame(sc, setup, W, H, light_grid=(128, 128), all_chunks=bool(all_chunks), reflect=bool(reflect),
+                   uniform_dims=(128, 128, 64), frame_cnt=2)
+    np.testing.assert_array_equal(got, want["image"])
+    assert want["image"].max() > 0 and want["is_shadowed"].sum() > 0

@@ -242,7 +242,9 @@ int ugrt_map_rays_to_light(ugrt_ctx *ctx, const float *d_t_value, const float *d
 			   const float *d_cam_position, float xM, float yM);
 /* processData(), per_frame_funcs.h:116: sorts d_map by light cell and writes the
  * chunk start indices; *num_chunks = h_numCudaBlocks (decision_data.h:264).
- * prefix_capacity entries must fit: n/64 + light cells + 1 always does. */
+ * prefix_capacity entries must fit: n/64 + light cells + 1 always does (a smaller map makes the call fail with
+ * UGRT_EINVAL; in the deferred form below the shadow tracer then traces nothing and ugrt_sort_rays_chunks reports
+ * the error). */
 int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity,
 		   unsigned *num_chunks);
 /* num_chunks may be NULL: the call then does not wait for the device; the count is passed on to

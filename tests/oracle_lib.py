@@ -24,7 +24,8 @@ def build():
 
 
 build()
-_lib = C.CDLL(LIB)
+# UGRT_ORACLE_LIB: an instrumented build of the oracle (make -C oracle asan)
+_lib = C.CDLL(os.environ.get("UGRT_ORACLE_LIB") or LIB)
 
 
 def _p(a):

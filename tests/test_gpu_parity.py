@@ -905,3 +905,39 @@ def test_full_size_animated_rebuild(ugrt, O, torch):
     r0.display(setup, shadows=True, reflect=True)
     ctx0.synchronize()
     assert (r0.image.cpu().numpy()[3 * a:3 * b] != want["image"][3 * a:3 * b]).any()
+
+
+@pytest.mark.parametrize("where", ["main", "side"])
+def test_overlapped_frame_survives_a_failed_frame(ugrt, O, torch, where):
+    """A call that raises in one two-stream frame (on the main thread or on the helper thread of the side stream)
+    must not leave the helper's result queue one entry behind: the next frames equal the sequential renderer's."""
+    s = scene(ugrt, "crash")
+    W, H, lg, ud = 256, 144, (64, 64), (32, 32, 16)
+    setup = setup_for(ugrt, s, "ref")
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    ctx2 = ugrt.Context(W, H, light_grid=lg, uniform_dims=ud)
+    r2 = ugrt.Renderer(ctx2, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True)
+    r2.display(setup, shadows=True, reflect=True)
+    target = ctx2 if where == "main" else r2.aux
+    name = "trace_primary" if where == "main" else "grid_build_uniform"
+    real = getattr(target, name)
+
+    def boom(*a, **k):
+        setattr(target, name, real)  # only this frame
+        raise RuntimeError("injected failure")
+
+    setattr(target, name, boom)
+    with pytest.raises(RuntimeError, match="injected"):
+        r2.display(setup, shadows=True, reflect=True)
+    r2.synchronize()
+    assert r2._done.empty()
+    for _ in range(2):
+        r2.display(setup, shadows=True, reflect=True)
+    r2.synchronize()
+    torch.cuda.synchronize()
+    for n in ("t", "is_shadowed", "hit_id", "hit_t", "intersect_id", "image"):
+        np.testing.assert_array_equal(getattr(r, n).cpu().numpy().view(np.uint8), getattr(r2, n).cpu().numpy().view(np.uint8),
+                                      err_msg=n)
+    r2.close()

@@ -23,7 +23,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libugrt.so")
+# UGRT_LIB: an instrumented build of the library (e.g. the AddressSanitizer build of the host translation unit
+# that tests/test_sanitizers.py runs); with UGRT_HOST_ONLY=1 such a build may lack the device entry points
+LIB_PATH = os.environ.get("UGRT_LIB") or os.path.join(_HERE, "libugrt.so")
+_HOST_ONLY = os.environ.get("UGRT_HOST_ONLY", "") == "1"
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -35,6 +38,8 @@ if not os.path.exists(LIB_PATH):
 # Device pointers are only valid inside ONE runtime, so torch's copy has to be the one in the
 # process: load it before libugrt.so resolves its own dependency.
 try:
+    if _HOST_ONLY:
+        raise ImportError("host-only")
     import torch  # noqa: F401
 except ImportError:  # host-only use (loader, camera, PPM) works without torch
     torch = None
@@ -149,6 +154,8 @@ PROTOTYPES = {
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():
+    if _HOST_ONLY and not hasattr(lib, _name):
+        continue
     _fn = getattr(lib, _name)  # AttributeError here = the library does not export what the header declares
     _fn.restype = _res
     _fn.argtypes = _args

@@ -722,6 +722,8 @@ static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const f
 // FrustumGrid::buildGrid, frustum_grid.h:210
 extern "C" int ugrt_grid_build_perspective(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int F)
 {
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_perspective: null context");
 	Grid &G = ctx->grid[UGRT_GRID_PERSPECTIVE];
 	int rc = build_prologue(ctx, G, d_facelist, d_vertlist, F, "grid_build_perspective");
 	if (rc)
@@ -750,6 +752,8 @@ extern "C" int ugrt_grid_build_perspective(ugrt_ctx *ctx, const int *d_facelist,
 extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int F,
 					 float xM, float yM)
 {
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_spherical: null context");
 	Grid &G = ctx->grid[UGRT_GRID_SPHERICAL];
 	int rc = build_prologue(ctx, G, d_facelist, d_vertlist, F, "grid_build_spherical");
 	if (rc)
@@ -779,8 +783,8 @@ extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, c
 extern "C" int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, const float *d_vertlist, int F,
 				       const float bbmin[3], const float bbmax[3])
 {
-	if (!bbmin || !bbmax)
-		return ugrt_fail(UGRT_EINVAL, "grid_build_uniform: null bounds");
+	if (!ctx || !bbmin || !bbmax)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_uniform: null argument");
 	Grid &G = ctx->grid[UGRT_GRID_UNIFORM];
 	int rc = build_prologue(ctx, G, d_facelist, d_vertlist, F, "grid_build_uniform");
 	if (rc)

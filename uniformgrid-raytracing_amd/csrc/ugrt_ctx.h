@@ -95,10 +95,13 @@ struct ugrt_ctx {
 	DevBuf sray;                                         // shadow tracer: rebuilt rays {direction, distance}, beam order
 	DevBuf citem;                                        // shadow tracer: light cell of every cull item
 	DevBuf sitem;                                        // shadow tracer: exact-pass item list (segment, beam|sub) x2
-	u32 *h_pinned = nullptr;      // 16 u32 of pinned host memory for small read-backs
+	// 32 u32 of pinned host memory for small read-backs: [0,1] narrow refs + wide triangles of the running build,
+	// [4..6] cells_used per grid, [8,9] refs_of, [10] candidate pairs, [11] chunks, [12] beams, [14..17] shadow work counters
+	u32 *h_pinned = nullptr;
 	u32 *d_small = nullptr;       // device scratch words (totals, counters, the direction table)
 	unsigned prof_mask = 0; // bit s = stage s is timed
 	unsigned chunk_capacity = 0; // prefix_capacity of the last ugrt_sort_rays
+	const unsigned *chunk_prefix = nullptr, *chunk_map = nullptr; // and the arrays it sorted / wrote
 	int opt[UGRT_OPT_COUNT];     // ugrt_ctx_set_option; -1 = the built-in default
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;

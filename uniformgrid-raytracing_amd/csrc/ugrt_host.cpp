@@ -78,9 +78,11 @@ int convert_index(int current_max, int index)
 	return index - 1;
 }
 
-double tok_atof(const char *delim)
+// (strtok_r: the parsers keep their position in a local, so scene loads are safe beside other threads, and the
+// MTL parser can run inside the OBJ parser's line loop)
+double tok_atof(const char *delim, char **save)
 {
-	char *t = strtok(nullptr, delim);
+	char *t = strtok_r(nullptr, delim, save);
 	return t ? atof(t) : 0.0;
 }
 
@@ -89,10 +91,10 @@ bool parse_mtl(const std::string &path, std::vector<Material> &out)
 	FILE *fp = fopen(path.c_str(), "r");
 	if (!fp)
 		return false;
-	char line[500];
+	char line[500], *save = nullptr;
 	bool open = false;
 	while (fgets(line, sizeof(line), fp)) {
-		char *tok = strtok(line, WS);
+		char *tok = strtok_r(line, WS, &save);
 		if (!tok || !strcmp(tok, "//") || !strcmp(tok, "#"))
 			continue;
 		if (!strcmp(tok, "newmtl")) {
@@ -105,7 +107,7 @@ bool parse_mtl(const std::string &path, std::vector<Material> &out)
 			m.glossy = 98;
 			m.shiny = 0;
 			m.refract_index = 1;
-			char *nm = strtok(nullptr, " \t");
+			char *nm = strtok_r(nullptr, " \t", &save);
 			m.name = nm ? nm : "";
 			out.push_back(m);
 			open = true;
@@ -113,31 +115,31 @@ bool parse_mtl(const std::string &path, std::vector<Material> &out)
 			continue;
 		} else if (!strcmp(tok, "Ka")) {
 			Material &m = out.back();
-			m.amb[0] = tok_atof(" ");
-			m.amb[1] = tok_atof(" ");
-			m.amb[2] = tok_atof(" ");
+			m.amb[0] = tok_atof(" ", &save);
+			m.amb[1] = tok_atof(" ", &save);
+			m.amb[2] = tok_atof(" ", &save);
 		} else if (!strcmp(tok, "Kd")) {
 			Material &m = out.back();
-			m.diff[0] = tok_atof(" \t");
-			m.diff[1] = tok_atof(" \t");
-			m.diff[2] = tok_atof(" \t");
+			m.diff[0] = tok_atof(" \t", &save);
+			m.diff[1] = tok_atof(" \t", &save);
+			m.diff[2] = tok_atof(" \t", &save);
 		} else if (!strcmp(tok, "Ks")) {
 			Material &m = out.back();
-			m.spec[0] = tok_atof(" \t");
-			m.spec[1] = tok_atof(" \t");
-			m.spec[2] = tok_atof(" \t");
+			m.spec[0] = tok_atof(" \t", &save);
+			m.spec[1] = tok_atof(" \t", &save);
+			m.spec[2] = tok_atof(" \t", &save);
 		} else if (!strcmp(tok, "Ns")) {
-			out.back().shiny = tok_atof(" \t");
+			out.back().shiny = tok_atof(" \t", &save);
 		} else if (!strcmp(tok, "d")) {
-			out.back().trans = tok_atof(" \t");
+			out.back().trans = tok_atof(" \t", &save);
 		} else if (!strcmp(tok, "r")) {
-			out.back().reflect = tok_atof(" \t");
+			out.back().reflect = tok_atof(" \t", &save);
 		} else if (!strcmp(tok, "sharpness")) {
-			out.back().glossy = tok_atof(" \t");
+			out.back().glossy = tok_atof(" \t", &save);
 		} else if (!strcmp(tok, "Ni")) {
-			out.back().refract_index = tok_atof(" \t");
+			out.back().refract_index = tok_atof(" \t", &save);
 		} else if (!strcmp(tok, "map_Ka")) {
-			char *t = strtok(nullptr, " \t");
+			char *t = strtok_r(nullptr, " \t", &save);
 			out.back().texture = t ? t : "";
 		}
 	}
@@ -164,14 +166,14 @@ bool parse_obj(const char *path, ObjFile &o)
 	std::string dir(path);
 	size_t slash = dir.find_last_of('/');
 	dir = (slash == std::string::npos) ? std::string() : dir.substr(0, slash + 1);
-	char line[500];
+	char line[500], *save = nullptr;
 	int current_material = -1;
 	while (fgets(line, sizeof(line), fp)) {
-		char *tok = strtok(line, WS);
+		char *tok = strtok_r(line, WS, &save);
 		if (!tok || tok[0] == '#')
 			continue;
 		if (!strcmp(tok, "v")) {
-			double x = tok_atof(WS), y = tok_atof(WS), z = tok_atof(WS);
+			double x = tok_atof(WS, &save), y = tok_atof(WS, &save), z = tok_atof(WS, &save);
 			o.v.push_back(x);
 			o.v.push_back(y);
 			o.v.push_back(z);
@@ -183,7 +185,7 @@ bool parse_obj(const char *path, ObjFile &o)
 			int idx[4] = { 0, 0, 0, 0 };
 			int cnt = 0;
 			char *t;
-			while ((t = strtok(nullptr, WS)) != nullptr) {
+			while ((t = strtok_r(nullptr, WS, &save)) != nullptr) {
 				if (cnt < 4)
 					idx[cnt] = atoi(t);
 				cnt++;
@@ -193,9 +195,9 @@ bool parse_obj(const char *path, ObjFile &o)
 				o.fidx.push_back(convert_index(nv, idx[k]));
 			o.fmat.push_back(current_material);
 		} else if (!strcmp(tok, "usemtl")) {
-			current_material = find_material(o.mtl, strtok(nullptr, WS));
+			current_material = find_material(o.mtl, strtok_r(nullptr, WS, &save));
 		} else if (!strcmp(tok, "mtllib")) {
-			char *fn = strtok(nullptr, WS);
+			char *fn = strtok_r(nullptr, WS, &save);
 			if (fn) {
 				// next to the .obj first, then relative to the cwd (reference behaviour)
 				if (!parse_mtl(dir + fn, o.mtl))
@@ -379,7 +381,13 @@ extern "C" int ugrt_scene_load_cache(ugrt_scene *s, const char *path)
 	char magic[8];
 	ugrt_scene t;
 	int32_t nm = 0;
-	const uint64_t lim = (uint64_t)1 << 33;
+	// no list can hold more elements than the file has bytes: a corrupt length never triggers a huge allocation
+	uint64_t lim = 0;
+	if (fseek(fp, 0, SEEK_END) == 0) {
+		const long sz = ftell(fp);
+		lim = sz > 0 ? (uint64_t)sz : 0;
+		rewind(fp);
+	}
 	bool ok = fread(magic, 1, 8, fp) == 8 && memcmp(magic, CACHE_MAGIC, 8) == 0 && fread(&nm, 4, 1, fp) == 1 &&
 		  fread(t.bbmin, 4, 3, fp) == 3 && fread(t.bbmax, 4, 3, fp) == 3 && get_vec(fp, t.vertexlist, lim) &&
 		  get_vec(fp, t.facelist, lim) && get_vec(fp, t.matidx, lim) && get_vec(fp, t.materiallist, lim) &&
@@ -387,6 +395,12 @@ extern "C" int ugrt_scene_load_cache(ugrt_scene *s, const char *path)
 	fclose(fp);
 	ok = ok && nm >= 0 && t.materiallist.size() == (size_t)nm * 6 && t.vertexlist.size() % 3 == 0 &&
 	     t.facelist.size() == t.matidx.size() * 3;
+	if (ok)
+		for (int m : t.matidx)
+			if (m >= nm) { // (negative = no material, as the loader leaves it)
+				ok = false;
+				break;
+			}
 	if (ok) {
 		const size_t nv = t.vertexlist.size() / 3;
 		for (int idx : t.facelist)
@@ -594,7 +608,7 @@ extern "C" int ugrt_write_ppm(const char *path, int W, int H, const unsigned cha
 	// one large buffer: the reference's 3*W*H fprintf calls are the slow part of its frame
 	std::string out;
 	out.reserve((size_t)W * H * 12 + 64);
-	char num[16];
+	char num[32];
 	out += "P3\n";
 	snprintf(num, sizeof(num), "%d %d\n", W, H);
 	out += num;

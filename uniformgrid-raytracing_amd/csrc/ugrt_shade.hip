@@ -163,6 +163,8 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 11, (u32 *)ctx->cbase.p + (ncell - 1), 4, hipMemcpyDeviceToHost, st));
 	ugrt_prof_end(ctx, UGRT_ST_SORT_RAYS);
 	ctx->chunk_capacity = prefix_capacity;
+	ctx->chunk_prefix = d_prefix_map;
+	ctx->chunk_map = d_map;
 	if (!num_chunks)
 		return UGRT_OK; // deferred: the count stays on the device (UGRT_CHUNKS_ON_DEVICE) until ugrt_sort_rays_chunks
 	return ugrt_sort_rays_chunks(ctx, num_chunks);

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 							     const u32 *__restrict__ span, const float *__restrict__ cmPt,
 							     u32 mbits, void *__restrict__ keys, u32 *__restrict__ vals,
 							     u32 *__restrict__ zero, u32 nzero,
-							     const u32 *__restrict__ nchunks_dev, u32 launch_cap)
+							     const u32 *__restrict__ nchunks_dev, u32 launch_cap, u32 prefix_cap)
 {
 	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
 	for (u32 z = i; z < nzero; z += gridDim.x * WL_THREADS)
@@ -601,6 +601,10 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 		return;
 	if (nchunks_dev) { // the chunk count never went to the host (UGRT_CHUNKS_ON_DEVICE): same rule, here
 		nchunks = *nchunks_dev;
+		// more chunks than the caller's prefix map holds: the host path refuses that (ugrt_sort_rays_chunks
+		// reports it); here nothing past the written entries is read and nothing is traced
+		if (nchunks > prefix_cap)
+			nchunks = 0;
 		const u32 lim = nchunks < launch_cap ? nchunks : launch_cap;
 		traced = launch_cap == 0xFFFFFFFFu ? nchunks : (lim ? lim - 1u : 0u);
 	}
@@ -1116,6 +1120,9 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if (on_device) {
 		if (!ctx->cbase.p)
 			return ugrt_fail(UGRT_EINVAL, "trace_shadow: UGRT_CHUNKS_ON_DEVICE without a ugrt_sort_rays before");
+		if (ctx->chunk_prefix != d_prefix_map || ctx->chunk_map != d_map)
+			return ugrt_fail(UGRT_EINVAL, "trace_shadow: UGRT_CHUNKS_ON_DEVICE refers to the last ugrt_sort_rays, which "
+						      "sorted other arrays");
 		nchunks_dev = (const u32 *)ctx->cbase.p + C; // inclusive scan of the chunks per light cell, last entry
 		traced = num_chunks;                          // the keys kernel applies the launch rule itself
 	} else if (launch_cap == 0xFFFFFFFFu) {
@@ -1181,14 +1188,14 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if (key64) {
 		hipLaunchKernelGGL(k_shadow_keys<true>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap);
+				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity);
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs64(ctx, (const u64 *)k0, (u64 *)k1, v0, v1, n, 30 + (int)cellbits)))
 			return rc;
 	} else {
 		hipLaunchKernelGGL(k_shadow_keys<false>, dim3((n + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap);
+				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity);
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits))))
 			return rc;

@@ -42,11 +42,14 @@ class BandGather:
         b, e = self.bands[r]
         return (e - b) * 8 * self.width * 3
 
-    def gather(self, image):
-        """image: uint8 [3*W*H] on the device.  Starts this frame's gather and returns: the collective runs
-        beside the next frame (it only reads the staging copy of the band made here), and the received bands
-        are placed into rank 0's image by the next call or by finish().  The renderer of rank 0 only ever
-        writes its own band, so the late placement cannot collide with the next frame."""
+    def gather(self, image, wait=False):
+        """image: uint8 [3*W*H] on the device.  Starts this frame's gather: the collective runs beside the next
+        frame (it only reads the staging copy of the band made here), and the received bands are placed into
+        rank 0's image by the next call or by finish().  The renderer of rank 0 only ever writes its own band, so
+        the late placement cannot collide with the next frame.
+        Returns the image only when it is COMPLETE (world == 1, or wait=True, which finishes the collective before
+        returning: what a caller that writes or shows every frame needs); otherwise None - until finish() rank
+        0's image holds its own band of this frame beside the other ranks' bands of the previous one."""
         if self.world == 1:
             return image
         self._complete()
@@ -56,7 +59,10 @@ class BandGather:
         self.send[:n].copy_(image[off:off + n])  # (device -> host when staging)
         self._work = self.dist.gather(self.send, self.recv, dst=0, async_op=True)
         self._image = image
-        return image
+        if wait:
+            self._complete()
+            return image
+        return None
 
     def finish(self):
         """Waits for the gather in flight; rank 0's image then holds every band of the last gathered frame."""

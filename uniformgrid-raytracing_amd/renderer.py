@@ -111,14 +111,29 @@ class Renderer:
         self.image = t.zeros(3 * N, dtype=t.uint8, device=ctx.device)
         self.cam_pos = ctx.empty(3, t.float32)
         # pinned staging for d_cam_position: a pageable-memory copy would make the host wait for the whole
-        # previous frame before it may enqueue the next one (the grid build's read-back, which follows in stream
-        # order, guarantees the staging buffer is free again by the next frame)
-        self._cam_pos_host = t.empty(3, dtype=t.float32).pin_memory()
+        # previous frame before it may enqueue the next one.  Two buffers alternate and an event behind each copy
+        # is waited for before the buffer is rewritten, so no other call has to synchronise for this to be safe
+        self._cam_pos_host = [t.empty(3, dtype=t.float32).pin_memory() for _ in range(2)]
+        self._cam_pos_done = [None, None]  # event behind the copy out of each staging buffer
+        self._cam_pos_turn = 0
         self.rays = self.active = self.hit_t = self.hit_id = None
         self.reflect_eps = float(reflect_eps)
         self._num_chunks = 0
         self.orig = None
         self.aspect = float(np.float32(ctx.width) / np.float32(ctx.height))
+
+    def _upload_cam_pos(self, worldori):
+        """main.cu:128 d_cam_position <- worldori, without a host wait in the steady state."""
+        t = self.ctx.torch
+        k = self._cam_pos_turn
+        self._cam_pos_turn = 1 - k
+        if self._cam_pos_done[k] is not None:
+            self._cam_pos_done[k].synchronize()  # the copy that read this buffer two frames ago
+        self._cam_pos_host[k].copy_(t.from_numpy(worldori[:3].copy()))
+        self.cam_pos.copy_(self._cam_pos_host[k], non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self.ctx.device))
+        self._cam_pos_done[k] = ev
 
     @property
     def num_chunks(self):
@@ -163,8 +178,7 @@ class Renderer:
         ctx.set_light_position(setup.shading_light)
         cam = make_camera(setup.camera, setup.fovy, self.aspect)
         # main.cu:128 d_cam_position <- worldori ; fillCoordinatesData
-        self._cam_pos_host.copy_(t.from_numpy(cam.worldori[:3].copy()))
-        self.cam_pos.copy_(self._cam_pos_host, non_blocking=True)
+        self._upload_cam_pos(cam.worldori)
         ctx.upload_camera(cam.camcoords)
         # build_frustum_grid
         ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
@@ -172,9 +186,10 @@ class Renderer:
         # FrustumTracer::trace
         ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed, self.intersect_id,
                           self.d_verts, self.d_faces)
+        # dd_camcoords is the light's from here on, shadows or not (main.cu:158-170: the shading kernels read it)
+        lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
+        ctx.upload_camera(lcam.camcoords)
         if shadows:
-            lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
-            ctx.upload_camera(lcam.camcoords)
             ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
             if self.shards is not None:
                 self._sharded(GRID_SPHERICAL,
@@ -229,17 +244,24 @@ class Renderer:
         # side stream: starts once the geometry of this frame is final on the main stream
         side.wait_stream(main)
 
+        status = {"primary_failed": False, "light_grid_failed": False}
+
         def side_job():
             try:
                 if shadows:
                     aux.upload_camera(lcam.camcoords)
                     aux.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
                     ev_light_grid.record(side)
+            except BaseException:
+                status["light_grid_failed"] = True  # the main thread must not wait for an event never recorded
+                raise
             finally:
                 light_grid_recorded.set()
             if reflect:
                 aux.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
                 primary_recorded.wait()
+                if status["primary_failed"]:
+                    return
                 side.wait_event(ev_primary)
                 aux.reflect_rays(self.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
                                  self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays,
@@ -249,33 +271,46 @@ class Renderer:
                               self.hit_t, self.hit_id)
 
         self._jobs.put(side_job)
+        failed = None
         try:
-            # main stream: the camera pass
-            ctx.set_light_position(setup.shading_light)
-            cam = make_camera(setup.camera, setup.fovy, self.aspect)
-            self._cam_pos_host.copy_(t.from_numpy(cam.worldori[:3].copy()))
-            self.cam_pos.copy_(self._cam_pos_host, non_blocking=True)
-            ctx.upload_camera(cam.camcoords)
-            ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
-            value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
-            ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed,
-                              self.intersect_id, self.d_verts, self.d_faces)
-            ev_primary.record(main)
+            try:
+                # main stream: the camera pass
+                ctx.set_light_position(setup.shading_light)
+                cam = make_camera(setup.camera, setup.fovy, self.aspect)
+                self._upload_cam_pos(cam.worldori)
+                ctx.upload_camera(cam.camcoords)
+                ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
+                value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
+                ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed,
+                                  self.intersect_id, self.d_verts, self.d_faces)
+                ev_primary.record(main)
+            except BaseException as e:
+                status["primary_failed"] = True  # the side job skips what depends on the primary hits
+                raise e
+            finally:
+                primary_recorded.set()
+            ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
+            if shadows:
+                ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
+                self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
+                light_grid_recorded.wait()
+                if status["light_grid_failed"]:
+                    raise RuntimeError("the light grid build on the side stream failed")
+                main.wait_event(ev_light_grid)
+                lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
+                ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir,
+                                 self.is_shadowed, self.d_map, self.prefix, self.cam_pos, self._num_chunks)
+        except BaseException as e:
+            failed = e
         finally:
-            primary_recorded.set()
-        ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
-        if shadows:
-            ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
-            self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
-            light_grid_recorded.wait()
-            main.wait_event(ev_light_grid)
-            lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
-            ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
-                             self.d_map, self.prefix, self.cam_pos, self._num_chunks)
-        err = self._done.get()  # the side stream's work is enqueued
+            # exactly one result per submitted job is consumed, whatever happened above: a result left in the
+            # queue would make the NEXT frame join the side stream before its own work was enqueued
+            err = self._done.get()
+        main.wait_stream(side)
+        if failed is not None:
+            raise failed
         if err is not None:
             raise err
-        main.wait_stream(side)
         if reflect:
             ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
                               self.d_matidx, self.d_matlist, self.d_reflect, self.num_materials, self.d_verts,

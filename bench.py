@@ -31,6 +31,40 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def kernel_source_hash():
+    """Hash of the device-code sources: ties a committed PMC profile (profiles/traffic.json) to the build it was taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "uniformgrid-raytracing_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload, W, H, scale, kernel):
+    """HBM bytes per launch of `kernel` and per frame from the committed rocprofv3 PMC passes, or (None, None, why).
+    The profile must have been taken on THIS build of the kernels: a stale number is refused, loudly."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None, "profiles/traffic.json is missing"
+    rec = json.load(open(tpath))
+    key = "%s:%dx%d:scale%g" % (workload, W, H, scale)
+    ent = rec.get(key)
+    if ent is None:
+        return None, None, "profiles/traffic.json has no entry %r (have %s)" % (key, sorted(rec))
+    if ent.get("kernel_source_hash") != kernel_source_hash():
+        return None, None, ("profiles/traffic.json entry %r was measured on kernel sources %s (%s), this build is %s: "
+                            "re-run tools/profile_round.sh" % (key, ent.get("kernel_source_hash"), ent.get("profile"),
+                                                               kernel_source_hash()))
+    per = ent.get("per_launch_bytes", {}).get(kernel)
+    if per is None:
+        return None, ent, "profile %s has no kernel %s" % (ent.get("profile"), kernel)
+    return per, ent, None
+
+
 def load_scene(ugrt, workload, scale, rank):
     """Generate the procedural scene, write it as .obj/.mtl/.mat and load it through the product's loader."""
     t0 = time.time()
@@ -75,8 +109,8 @@ def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
     # candidate references of each beam once per 64-ray sub-group.
     st = ctx.stats()
     out["stage_shadow_A11"] = 24 * n + 8 * nch + 52 * int(sp.sum().item())
-    out["shadow_cull"] = 52 * int(st[6]) + 32 * int(st[1])
-    out["trace_shadow"] = 24 * n + 52 * int(st[7])
+    out["_units_shadow_cull_tests"] = int(st[6])      # (triangle, beam) interval tests of the cull pass
+    out["_units_shadow_candidates_staged"] = int(st[7])  # candidate references staged by the exact pass
     tests, cells_visited, active = dda_counts
     out["trace_dda"] = 48 * active + 8 * cells_visited + 52 * tests
     out["_R_perspective"], out["_R_spherical"] = gi.total_refs, lgi.total_refs
@@ -89,12 +123,12 @@ def algorithmic_bytes(torch, ugrt, ctx, r, dda_counts):
 
 
 def cpu_baseline(ugrt, s, setup, W, H, lg, udims, seconds):
-    """The oracle (CPU restatement, kind "port") on the host cores: grid builds timed in full,
-    tracing on a band of tile rows, scaled to the frame."""
+    """The oracle (CPU restatement, kind "port") on the host cores, twice as BASELINE.md asks: all cores and one
+    thread.  Grid builds are timed in full, tracing on a band of tile rows grown to about `seconds` of wall time
+    and scaled to the frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O  # the checker, used here only as the timed CPU baseline
 
-    cores = O.set_threads(os.cpu_count() or 1)
     nby = H // 8
     fixed = ("build_spherical", "build_uniform")
 
@@ -106,23 +140,31 @@ def cpu_baseline(ugrt, s, setup, W, H, lg, udims, seconds):
         tf = sum(fr["times"][k] for k in fixed)
         return wall, tf, rays
 
-    mid = nby // 2
-    nrows, wall, tf, rays, rows = 2, 0.0, 0.0, 0, (mid, mid + 2)
-    for _ in range(4):  # grow the band until the sample costs about `seconds` of CPU time (or is the frame)
-        lo = max(0, mid - nrows // 2)
-        rows = (lo, min(nby, lo + nrows))
-        wall, tf, rays = run(rows)
-        if wall >= 0.6 * seconds or rows[1] - rows[0] >= nby:
-            break
-        per_row = max((wall - tf) / float(rows[1] - rows[0]), 1e-4)
-        nrows = int(max(nrows + 1, min(nby, (seconds - tf) / per_row)))
-    scale = nby / float(rows[1] - rows[0])
-    t_full = tf + (wall - tf) * scale
-    value = rays * scale / t_full / 1e6
-    return dict(value=round(value, 4), unit="Mrays/s", cores=cores, kind="port",
-                sample="oracle frame on tile rows [%d,%d) of %d (%.1f s wall; spherical+uniform grid builds "
-                       "%.2f s counted once, the rest scaled x%.2f to the frame)"
-                       % (rows[0], rows[1], nby, wall, tf, scale))
+    def sample(threads, budget):
+        cores = O.set_threads(threads)
+        mid = nby // 2
+        nrows, wall, tf, rays, rows = 2, 0.0, 0.0, 0, (mid, mid + 2)
+        for _ in range(4):  # grow the band until the sample costs about `budget` seconds (or is the frame)
+            lo = max(0, mid - nrows // 2)
+            rows = (lo, min(nby, lo + nrows))
+            wall, tf, rays = run(rows)
+            if wall >= 0.6 * budget or rows[1] - rows[0] >= nby:
+                break
+            per_row = max((wall - tf) / float(rows[1] - rows[0]), 1e-4)
+            nrows = int(max(nrows + 1, min(nby, (budget - tf) / per_row)))
+        scale = nby / float(rows[1] - rows[0])
+        t_full = tf + (wall - tf) * scale
+        value = rays * scale / t_full / 1e6
+        return dict(value=round(value, 4), unit="Mrays/s", cores=cores,
+                    sample="oracle frame on tile rows [%d,%d) of %d (%.1f s wall; spherical+uniform grid builds "
+                           "%.2f s counted once, the rest scaled x%.2f to the frame)"
+                           % (rows[0], rows[1], nby, wall, tf, scale))
+
+    allc = sample(os.cpu_count() or 1, seconds)
+    one = sample(1, seconds)
+    out = dict(allc, kind="port")
+    out["one_thread"] = dict(value=one["value"], unit="Mrays/s", cores=1, sample=one["sample"])
+    return out
 
 
 def main():
@@ -140,6 +182,10 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream: every stage after the other (default: light/uniform grid builds and the bounce "
                          "on a second stream beside the camera and shadow passes)")
+    ap.add_argument("--repeats", type=int, default=4, help="extra untimed repetitions of the K steps (spread of the figure)")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="independent frames in flight: F renderers (own contexts, buffers and streams) take the steps in "
+                         "turn, so the GPU works on the tail of one frame and the head of the next")
     ap.add_argument("--config3", action="store_true",
                     help="BASELINE configs[3] as stated: ONE 3840x2160 frame cut into N bands (strong scaling)")
     ap.add_argument("--shard-builds", action="store_true",
@@ -202,10 +248,18 @@ def main():
         if args.shard_builds else None
     r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
                       overlap=not args.no_overlap and shards is None, shards=shards)
+    renderers = [r]
+    for i in range(1, max(1, args.frames_in_flight)):
+        with torch.cuda.stream(torch.cuda.Stream(ctx.device)):
+            cx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
+            renderers.append(ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
+                                           overlap=not args.no_overlap and shards is None, shards=shards))
+            renderers[-1]._stream = torch.cuda.current_stream(ctx.device)
     for kv in args.opt:
         k, v = kv.split("=")
-        for c in [ctx] + ([r.aux] if r.aux is not None else []):
-            c.set_option(k, int(v))
+        for rr in renderers:
+            for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
+                c.set_option(k, int(v))
     gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world, host_staging=rehearse)
 
     reflect = not args.no_reflect
@@ -213,12 +267,20 @@ def main():
         r.init_orig_list(s["animated_size"], s["animated_offset"])
     frame_no = [0]
 
+    turn = [0]
+
     def step():
+        rr = renderers[turn[0] % len(renderers)]
+        turn[0] += 1
         if args.animate:  # Model::rotate_bunny(lightRotFactor), main.cu:68 + per_frame_funcs.h:15
-            r.rotate_bunny(1.81 + 0.05 * frame_no[0])
+            rr.rotate_bunny(1.81 + 0.05 * frame_no[0])
             frame_no[0] += 1
-        r.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
-        gather.gather(r.image)
+        if getattr(rr, "_stream", None) is not None:
+            with torch.cuda.stream(rr._stream):
+                rr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+        else:
+            rr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+        gather.gather(rr.image)
 
     for _ in range(max(1, args.warmup)):
         step()
@@ -271,12 +333,24 @@ def main():
     for _ in range(args.steps):
         step()
     gather.finish()  # the last frame's bands are in rank 0's image
-    r.synchronize()
+    for rr in renderers:
+        rr.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     prof = merged_prof()
+    # spread of the figure: the same K steps a few more times, outside the reported region
+    repeats = []
+    for _ in range(args.repeats):
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        gather.finish()
+        r.synchronize()
+        torch.cuda.synchronize()
+        repeats.append((time.perf_counter() - r0) / args.steps * 1e3)
     # untimed pass: the full stage table (with two streams the stages overlap: their sum exceeds the frame)
     for c in profiled:
         c.prof_enable(True)
@@ -313,30 +387,53 @@ def main():
             stages[k] = dict(ms_per_launch=v[0] / v[1], launches_per_step=v[1] / float(args.steps),
                              ms_per_step=v[0] / args.steps)
     gpu_ms = sum(v["ms_per_step"] for v in stages.values())
-    dom = max(("trace_primary", "shadow_cull", "trace_shadow", "trace_dda"),
+    # the roofline figure is quoted on the longest tracer whose algorithmic bytes are bytes the kernel's algorithm
+    # really addresses (every staged reference of the primary pass, every cell and triangle a bounce ray meets); the
+    # two shadow kernels only have a work count in units of the reference's algorithm (work_reduction below)
+    dom = max(("trace_primary", "trace_dda") if reflect else ("trace_primary",),
               key=lambda k: stages.get(k, {}).get("ms_per_step", 0))
     dom_ms = stages[dom]["ms_per_launch"]
     achieved = abytes[dom] / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath))
-            key = "%s:%s:%dx%d:scale%g" % (args.workload, dom, W, H, args.scale)
-            traffic = rec.get(key)
-        except Exception:
-            traffic = None
+    kname = {"trace_primary": "k_trace_primary", "trace_shadow": "k_trace_shadow", "shadow_cull": "k_shadow_cull",
+             "trace_dda": "k_trace_dda"}[dom]
+    traffic, tent, twhy = pmc_traffic(args.workload, W, H, args.scale, kname) if world == 1 else (None, None, "N > 1")
+    if twhy:
+        log("[bench] roofline.traffic = null: " + twhy)
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    algorithmic_bytes_per_launch=int(abytes[dom]), ms_per_launch=round(dom_ms, 4),
+                    traffic_source=(dict(profile=tent["profile"], kernel_source_hash=tent["kernel_source_hash"])
+                                    if tent else None),
+                    traffic_error=twhy,
+                    note="achieved = algorithmic bytes of THIS kernel (SURVEY 8(d): 48 B per ray + 8 B per cell visited + "
+                         "52 B per triangle tested, as the per-ray algorithm counts them) / its launch time from hipEvents "
+                         "on its own stream inside the timed loop; traffic = HBM bytes per launch from rocprofv3 PMC "
+                         "passes of the same build (2*FETCH_SIZE + WRITE_SIZE, KiB units)")
+    # whole-frame HBM figure: all kernels' PMC bytes of one frame over the frame time
+    frame_hbm = None
+    if tent and tent.get("frame_bytes"):
+        fb = float(tent["frame_bytes"])
+        frame_hbm = dict(bytes=int(fb), GBps=round(fb / (elapsed / args.steps) / 1e9, 1),
+                         frac=round(fb / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4), profile=tent["profile"])
+    # NOT a roofline: how much less data the restructured shadow stage moves than the reference's algorithm would
+    # (every 64-ray chunk re-stages its cell's whole list).  The "GB/s" of that formula exceed the HBM
+    # peak because most of those bytes are never moved; reported as a work-reduction factor.
     a11_ms = sum(stages.get(k, {}).get("ms_per_step", 0.0) for k in ("shadow_prep", "shadow_cull", "trace_shadow"))
-    roofline_stage = dict(stage="shadow (SURVEY A11: prep + cull + exact kernels)", algorithmic_bytes=int(abytes["stage_shadow_A11"]),
-                          ms=round(a11_ms, 4), achieved=round(abytes["stage_shadow_A11"] / (a11_ms * 1e-3) / 1e9, 2),
-                          unit="GB/s", frac=round(abytes["stage_shadow_A11"] / (a11_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) \
-        if a11_ms > 0 else None
-    roofline = dict(bound="hbm", kernel={"trace_primary": "k_trace_primary", "trace_shadow": "k_trace_shadow",
-                                         "shadow_cull": "k_shadow_cull", "trace_dda": "k_trace_dda"}[dom],
-                    achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
-                    traffic=traffic, algorithmic_bytes_per_launch=int(abytes[dom]), ms_per_launch=round(dom_ms, 4),
-                    note="algorithmic bytes: SURVEY 8(d) convention (a staged reference = 52 B, cache/LDS reuse not "
-                         "discounted) applied to the units THIS kernel processes; DESIGN.md section 5/8. traffic = PMC")
+    work_reduction = None
+    if a11_ms > 0:
+        ref_bytes = abytes["stage_shadow_A11"]
+        moved = None
+        if tent:
+            pl = tent.get("per_frame_bytes", {})
+            mv = [pl.get(k) for k in ("k_shadow_keys", "k_shadow_boxes", "k_shadow_cull", "k_trace_shadow")]
+            moved = int(sum(x for x in mv if x)) if any(mv) else None
+        work_reduction = dict(stage="shadow (SURVEY A11: regroup + cull + exact kernels)",
+                              reference_algorithm_bytes=int(ref_bytes), ms=round(a11_ms, 4),
+                              pmc_bytes_of_the_stage_kernels=moved,
+                              bytes_not_moved_factor=(round(ref_bytes / float(moved), 1) if moved else None),
+                              note="reference_algorithm_bytes / ms = %.0f GB/s would be %.2f x the HBM peak: it is a count of "
+                                   "work the restructured stage avoids, not a bandwidth"
+                                   % (ref_bytes / (a11_ms * 1e-3) / 1e9, ref_bytes / (a11_ms * 1e-3) / 1e9 / HBM_PEAK_GBS))
 
     cpu = None
     if world == 1 and args.cpu_seconds > 0:
@@ -374,8 +471,10 @@ def main():
             "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",
         },
         "roofline": roofline,
-        "roofline_stage": roofline_stage,
+        "frame_hbm": frame_hbm,
+        "work_reduction": work_reduction,
         "cpu_baseline": cpu,
+        "repeat_ms_per_step": [round(x, 4) for x in repeats],
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},

@@ -24,6 +24,7 @@ enum {
 	UGRT_OPT_DDA_COOP,         // "dda_coop": list length from which a lone ray's cell is tested by the whole wave
 	UGRT_OPT_DDA_KERNEL,       // "dda_kernel": 0 = beam kernel, 1 = per-ray kernel of round 1
 	UGRT_OPT_DDA_CULL_MIN,     // "dda_cull_min": list length from which a shared cell is culled before the exact tests
+	UGRT_OPT_DDA_BLOCKS,       // "dda_blocks": upper bound of the persistent waves of ugrt_trace_dda
 	UGRT_OPT_PRIMARY_SEG,      // "primary_seg"
 	UGRT_OPT_SHADOW_BEAM,      // "shadow_beam"
 	UGRT_OPT_SHADOW_XSEG,      // "shadow_xseg"

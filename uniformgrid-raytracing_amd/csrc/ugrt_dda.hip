@@ -860,7 +860,11 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	const u32 CULL_MIN = ctx->opt[UGRT_OPT_DDA_CULL_MIN] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_MIN] : 8u;
 	if (DDA_RPW > 64u)
 		DDA_RPW = 64u;
-	const int blocks = launch_blocks_for((u32)ctx->npix / DDA_RPW + 1u);
+	// the launch is persistent (groups of rays are drawn from a ticket); "dda_blocks" caps its waves, which a context
+	// that runs beside another stream's kernels uses to leave registers and LDS of every CU to them
+	int blocks = launch_blocks_for((u32)ctx->npix / DDA_RPW + 1u);
+	if (ctx->opt[UGRT_OPT_DDA_BLOCKS] > 0 && blocks > ctx->opt[UGRT_OPT_DDA_BLOCKS])
+		blocks = ctx->opt[UGRT_OPT_DDA_BLOCKS];
 #define UGRT_LAUNCH_DDA(CNTV, RECV, DC)                                                                               \
 	do {                                                                                                          \
 		if (beam)                                                                                             \

@@ -68,8 +68,11 @@ class Renderer:
                                    rows=ctx.rows, flags=int(ctx.cfg.flags),
                                    uniform_dims=tuple(ctx.cfg.uniform_dims[k] for k in range(3)),
                                    slabs=int(ctx.cfg.slabs))
-            # the bounce runs beside the shadow pass: fewer, fuller waves leave the main stream more of the chip
+            # the bounce runs beside the ray sort and the shadow pass and has slack: four persistent waves per CU leave
+            # the registers and LDS of every CU to the main stream's workgroups (with the whole chip taken by
+            # the bounce's waves, a sort pass of the main stream waited 0.2 ms for room)
             self.aux.set_option("dda_rays_per_wave", 64)
+            self.aux.set_option("dda_blocks", 1024)
             import queue
             import threading
 

@@ -183,9 +183,13 @@ def main():
                     help="one stream: every stage after the other (default: light/uniform grid builds and the bounce "
                          "on a second stream beside the camera and shadow passes)")
     ap.add_argument("--repeats", type=int, default=4, help="extra untimed repetitions of the K steps (spread of the figure)")
-    ap.add_argument("--frames-in-flight", type=int, default=1,
+    ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="independent frames in flight: F renderers (own contexts, buffers and streams) take the steps in "
-                         "turn, so the GPU works on the tail of one frame and the head of the next")
+                         "turn, so the GPU works on the tail of one frame and the head of the next (1 = a frame is "
+                         "finished before the next one starts; that figure is reported too, as latency)")
+    ap.add_argument("--waiting-builds", action="store_true",
+                    help="grid builds and the shadow pass read their counts back as the reference does (default: option "
+                         "async_build, no host wait inside a frame)")
     ap.add_argument("--config3", action="store_true",
                     help="BASELINE configs[3] as stated: ONE 3840x2160 frame cut into N bands (strong scaling)")
     ap.add_argument("--shard-builds", action="store_true",
@@ -255,7 +259,8 @@ def main():
             renderers.append(ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
                                            overlap=not args.no_overlap and shards is None, shards=shards))
             renderers[-1]._stream = torch.cuda.current_stream(ctx.device)
-    for kv in args.opt:
+    opts = ([] if args.waiting_builds else ["async_build=1"]) + args.opt
+    for kv in opts:
         k, v = kv.split("=")
         for rr in renderers:
             for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
@@ -264,7 +269,8 @@ def main():
 
     reflect = not args.no_reflect
     if args.animate:
-        r.init_orig_list(s["animated_size"], s["animated_offset"])
+        for rr in renderers:
+            rr.init_orig_list(s["animated_size"], s["animated_offset"])
     frame_no = [0]
 
     turn = [0]
@@ -313,7 +319,8 @@ def main():
     # dominant kernel's live launch time); every other stage is timed in a separate, untimed pass below,
     # because ~40 event pairs per frame would themselves cost about 7 % of the frame.
     tracers = ("trace_primary", "shadow_cull", "trace_shadow", "trace_dda")
-    profiled = [ctx] + ([r.aux] if r.aux is not None else [])  # events are recorded on the stream a kernel runs on
+    # events are recorded on the stream a kernel runs on
+    profiled = [c for rr in renderers for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else [])]
 
     def merged_prof():
         out = {}
@@ -334,7 +341,7 @@ def main():
         step()
     gather.finish()  # the last frame's bands are in rank 0's image
     for rr in renderers:
-        rr.synchronize()
+        rr.synchronize()  # (raises if an asynchronous build or shadow pass overflowed its estimate: no silent loss)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -348,9 +355,22 @@ def main():
         for _ in range(args.steps):
             step()
         gather.finish()
-        r.synchronize()
+        for rr in renderers:
+            rr.synchronize()
         torch.cuda.synchronize()
         repeats.append((time.perf_counter() - r0) / args.steps * 1e3)
+    # latency: the same K steps with ONE frame in flight (every frame is finished before the next one is started)
+    latency_ms = None
+    if len(renderers) > 1:
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            renderers[0].display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+            gather.gather(renderers[0].image)
+        gather.finish()
+        renderers[0].synchronize()
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - r0) / args.steps * 1e3
     # untimed pass: the full stage table (with two streams the stages overlap: their sum exceeds the frame)
     for c in profiled:
         c.prof_enable(True)
@@ -359,7 +379,8 @@ def main():
     for _ in range(nfull):
         step()
     gather.finish()
-    r.synchronize()
+    for rr in renderers:
+        rr.synchronize()
     prof_full = merged_prof()
     for c in profiled:
         c.prof_enable(False)
@@ -465,7 +486,9 @@ def main():
             "frames_per_s": round(args.steps / elapsed, 2),
             "rays_per_frame": int(rays_total),
             "tile": 8, "light_grid": list(lg), "uniform_grid": list(udims),
-            "streams": 1 if (args.no_overlap or args.shard_builds) else 2,
+            "streams": (1 if (args.no_overlap or args.shard_builds) else 2) * len(renderers),
+            "frames_in_flight": len(renderers),
+            "host_waits_inside_a_frame": bool(args.waiting_builds),
             "grid_builds": "light + uniform grid in %d shards of the triangle list, all-gathered and merged" % world
                            if args.shard_builds else "replicated per rank",
             "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",
@@ -475,6 +498,7 @@ def main():
         "work_reduction": work_reduction,
         "cpu_baseline": cpu,
         "repeat_ms_per_step": [round(x, 4) for x in repeats],
+        "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},

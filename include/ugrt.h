@@ -42,7 +42,9 @@ enum {
 	UGRT_ENODEV = 2, /* no usable HIP device */
 	UGRT_EHIP = 3,   /* a HIP runtime call failed */
 	UGRT_EIO = 4,    /* file could not be opened / parsed */
-	UGRT_ENOMEM = 5
+	UGRT_ENOMEM = 5,
+	UGRT_EOVERFLOW = 6 /* option "async_build": a call's data-dependent size exceeded the room estimated from the call
+			      before; returned by ugrt_ctx_synchronize, the frames since the last one are to be repeated */
 };
 
 /* flags in ugrt_config.flags */
@@ -187,7 +189,14 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * cell is tested by the whole wave / a shared cell is culled before the exact tests; "primary_seg" triangles
  * per primary work item; "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits",
  * "shadow_key64" shape the shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix
- * sort instead of the built-in one. */
+ * sort instead of the built-in one.
+ * "async_build" 1: the grid builds and ugrt_trace_shadow stop waiting for the device.  The reference reads
+ * total_triangles back to size its lists (frustum_grid.h:254); here the second and later builds of a grid size
+ * buffers and launches by what the build before needed plus a quarter, every kernel takes the real counts from
+ * device memory, and a count that does not fit raises a flag instead of writing out of bounds:
+ * ugrt_ctx_synchronize then returns UGRT_EOVERFLOW once (the frames since the last synchronisation are
+ * incomplete) and the next calls run in the waiting form again, which sizes everything exactly.
+ * ugrt_grid_info.total_refs of such a build is final once the stream has been synchronised. */
 int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value);
 int ugrt_ctx_synchronize(ugrt_ctx *ctx);
 void ugrt_ctx_destroy(ugrt_ctx *ctx);

@@ -941,3 +941,41 @@ def test_overlapped_frame_survives_a_failed_frame(ugrt, O, torch, where):
         np.testing.assert_array_equal(getattr(r, n).cpu().numpy().view(np.uint8), getattr(r2, n).cpu().numpy().view(np.uint8),
                                       err_msg=n)
     r2.close()
+
+
+def test_async_builds_equal_the_waiting_form(ugrt, O, torch):
+    """Option "async_build": no call of the frame waits for the device (the counts the reference reads back stay
+    there); grids, flags and the image of later frames are those of the waiting form, ugrt_grid_info.total_refs is
+    right after a synchronisation, and a capacity that does not fit is reported by ugrt_ctx_synchronize."""
+    s = scene(ugrt, "crash")
+    W, H, lg, ud = 256, 144, (64, 64), (32, 32, 16)
+    setup = setup_for(ugrt, s, "ref")
+    ctx, r = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    ctx2, r2 = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    ctx2.set_option("async_build", 1)
+    for _ in range(3):  # the first frame waits (no estimate yet), the others do not
+        r2.display(setup, shadows=True, reflect=True)
+    ctx2.synchronize()
+    for which in (ugrt.GRID_PERSPECTIVE, ugrt.GRID_SPHERICAL, ugrt.GRID_UNIFORM):
+        a, b = ctx.grid_arrays(which), ctx2.grid_arrays(which)
+        assert a[4].total_refs == b[4].total_refs and a[4].cells_used == b[4].cells_used
+        for x, y in zip(a[:4], b[:4]):
+            np.testing.assert_array_equal(u32(x), u32(y))
+    for n in ("t", "is_shadowed", "hit_id", "hit_t", "intersect_id", "image"):
+        np.testing.assert_array_equal(getattr(r, n).cpu().numpy().view(np.uint8), getattr(r2, n).cpu().numpy().view(np.uint8),
+                                      err_msg=n)
+    assert ctx2.stats()[1] == ctx.stats()[1]
+    # a scene that suddenly needs far more references than the frame before: reported, then repaired
+    big = ugrt.scenes.crash(scale=0.08)
+    r3 = ugrt.Renderer(ctx2, big["verts"], big["faces"], big["matidx"], big["mat_list"], big["reflect"])
+    r3.display(setup_for(ugrt, big, "ref"), shadows=True, reflect=True)
+    with pytest.raises(ugrt.UgrtError, match="asynchronous"):
+        ctx2.synchronize()
+    r3.display(setup_for(ugrt, big, "ref"), shadows=True, reflect=True)  # waits, sizes exactly
+    ctx2.synchronize()
+    ctx3, r4 = make(ugrt, big, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    r4.display(setup_for(ugrt, big, "ref"), shadows=True, reflect=True)
+    ctx3.synchronize()
+    np.testing.assert_array_equal(r3.image.cpu().numpy(), r4.image.cpu().numpy())

@@ -46,7 +46,7 @@ except ImportError:  # host-only use (loader, camera, PPM) works without torch
 
 lib = C.CDLL(LIB_PATH)
 
-UGRT_OK, UGRT_EINVAL, UGRT_ENODEV, UGRT_EHIP, UGRT_EIO, UGRT_ENOMEM = range(6)
+UGRT_OK, UGRT_EINVAL, UGRT_ENODEV, UGRT_EHIP, UGRT_EIO, UGRT_ENOMEM, UGRT_EOVERFLOW = range(7)
 FLAG_SHADOW_ALL_CHUNKS = 1
 FLAG_COUNT_WORK = 2
 FLAG_STATIC_GEOMETRY = 4

@@ -330,11 +330,17 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const 
 // in LDS and its threads search that (a 20-step search of the global scan per REFERENCE diverges to 64
 // cache lines per wave in its last steps and was bound by the address path, not by bytes).
 #define FILL_LDS 1024
+// (counts that the host does not know - an asynchronous build - are read from `rw` = {narrow references, wide
+// triangles}, already checked against the capacities by k_build_check)
 __global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restrict__ scan, int F, u32 R, u32 nparts,
-							       u32 *__restrict__ parts)
+							       u32 *__restrict__ parts, const u32 *__restrict__ rw)
 {
+	if (rw) {
+		R = rw[0];
+		nparts = (R + BUILD_THREADS - 1) / BUILD_THREADS;
+	}
 	const u32 b = blockIdx.x * BUILD_THREADS + threadIdx.x;
-	if (b > nparts)
+	if (b > nparts || R == 0u)
 		return;
 	u32 target = b * BUILD_THREADS; // first reference of workgroup b; parts[nparts] closes the last one
 	if (target >= R)
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restr
 __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
 							 const u32 *__restrict__ parts, u32 R, int ny, int nz,
 							 u32 *__restrict__ keys, u32 *__restrict__ vals,
-							 u32 *__restrict__ zero, u32 nzero)
+							 u32 *__restrict__ zero, u32 nzero, const u32 *__restrict__ rw)
 {
 	__shared__ u32 s_scan[FILL_LDS];
 	const u32 r = blockIdx.x * BUILD_THREADS + threadIdx.x;
@@ -361,6 +367,10 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ 
 	// instead of by a fill of their own
 	for (u32 i = r; i < nzero; i += gridDim.x * BUILD_THREADS)
 		zero[i] = 0;
+	if (rw)
+		R = rw[0];
+	if (blockIdx.x * BUILD_THREADS >= R)
+		return; // (uniform per workgroup; an asynchronous launch is sized by the capacity)
 	const int f_first = (int)parts[blockIdx.x], f_last = (int)parts[blockIdx.x + 1];
 	const int nrun = f_last - f_first + 1;
 	const bool in_lds = nrun <= FILL_LDS;
@@ -406,8 +416,11 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ 
 // frustum_grid.h:334) in one pass over the sorted keys: run heads record the
 // run start, run tails the run end; used[0] counts the runs.
 __global__ __launch_bounds__(BUILD_THREADS) void k_bounds(const u32 *__restrict__ keys, u32 R,
-							   u32 *__restrict__ cstart, u32 *__restrict__ cend)
+							   u32 *__restrict__ cstart, u32 *__restrict__ cend,
+							   const u32 *__restrict__ rw)
 {
+	if (rw)
+		R = rw[0];
 	u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (i >= R)
 		return;
@@ -426,7 +439,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_bounds(const u32 *__restrict_
 // screen grid); every active cell also holds the W wide triangles.
 struct WideBox {
 	u32 W, ny, nz, ylo, yhi;
+	const u32 *rw; // asynchronous build: {narrow references, wide triangles} on the device (W above is unused then)
 };
+__device__ __forceinline__ u32 d_wide_count(const WideBox &wb) { return wb.rw ? wb.rw[1] : wb.W; }
 
 __device__ __forceinline__ bool d_cell_active(const WideBox &wb, u32 c)
 {
@@ -440,10 +455,11 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_span(const u32 *__restrict__ 
 	// grid-stride on a few hundred workgroups: each ends with ONE add on `used` (a workgroup per 256 cells
 	// meant 4096 same-address atomics for the 2^20-cell uniform grid, 0.04 ms)
 	u32 mine = 0;
+	const u32 W = d_wide_count(wb);
 	for (u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x; c < C; c += gridDim.x * BUILD_THREADS) {
 		u32 sp = span_io[c] - cstart[c]; // span_io holds the run end on entry
-		if (wb.W && d_cell_active(wb, c))
-			sp += wb.W;
+		if (W && d_cell_active(wb, c))
+			sp += W;
 		span_io[c] = sp;
 		mine += sp != 0u ? 1u : 0u;
 	}
@@ -465,8 +481,10 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_span(const u32 *__restrict__ 
 
 // ascending order of the (few) wide triangle ids: rank = number of smaller ids
 __global__ __launch_bounds__(BUILD_THREADS) void k_wide_rank(const u32 *__restrict__ wl, u32 W,
-							      u32 *__restrict__ sorted)
+							      u32 *__restrict__ sorted, const u32 *__restrict__ rw)
 {
+	if (rw)
+		W = rw[1];
 	u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (i >= W)
 		return;
@@ -507,19 +525,24 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_merge_narrow(const u32 *__res
 								 u32 *__restrict__ okeys, u32 *__restrict__ ovals)
 {
 	__shared__ u32 s_w[MERGE_LDS];
-	const bool w_lds = wb.W <= MERGE_LDS;
+	const u32 W = d_wide_count(wb);
+	if (wb.rw)
+		Rn = wb.rw[0];
+	if (blockIdx.x * BUILD_THREADS >= Rn)
+		return;
+	const bool w_lds = W <= MERGE_LDS;
 	if (w_lds)
-		for (u32 k = threadIdx.x; k < wb.W; k += BUILD_THREADS)
+		for (u32 k = threadIdx.x; k < W; k += BUILD_THREADS)
 			s_w[k] = wl[k];
 	__syncthreads();
 	const u32 j = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (j >= Rn)
 		return;
 	const u32 c = nkeys[j], id = nvals[j];
-	const u32 wp2 = d_pow2_ge(wb.W);
+	const u32 wp2 = d_pow2_ge(W);
 	u32 lb = 0;
-	if (d_cell_active(wb, c))
-		lb = w_lds ? d_lower_bound(s_w, wb.W, wp2, id) : d_lower_bound(wl, wb.W, wp2, id);
+	if (W && d_cell_active(wb, c))
+		lb = w_lds ? d_lower_bound(s_w, W, wp2, id) : d_lower_bound(wl, W, wp2, id);
 	const u32 pos = offset[c] + (j - cstart[c]) + lb;
 	ovals[pos] = id;
 	okeys[pos] = c;
@@ -533,10 +556,13 @@ __global__ __launch_bounds__(64) void k_merge_wide(const u32 *__restrict__ nvals
 {
 	__shared__ u32 s_n[MERGE_LDS];
 	const u32 lane = threadIdx.x;
+	const u32 W = d_wide_count(wb);
+	if (W == 0u)
+		return;
 	for (u32 c = blockIdx.x; c < C; c += gridDim.x) {
 		if (!d_cell_active(wb, c))
 			continue;
-		const u32 ns = span[c] - wb.W;
+		const u32 ns = span[c] - W;
 		const u32 *nv = nvals + cstart[c];
 		const u32 out = offset[c];
 		const bool n_lds = ns <= MERGE_LDS;
@@ -546,7 +572,7 @@ __global__ __launch_bounds__(64) void k_merge_wide(const u32 *__restrict__ nvals
 			for (u32 i = lane; i < ns; i += 64u)
 				s_n[i] = nv[i];
 		__syncthreads();
-		for (u32 k = lane; k < wb.W; k += 64u) {
+		for (u32 k = lane; k < W; k += 64u) {
 			const u32 id = wl[k];
 			const u32 lb = n_lds ? d_lower_bound(s_n, ns, np2, id) : d_lower_bound(nv, ns, np2, id);
 			const u32 pos = out + k + lb;
@@ -568,12 +594,152 @@ static int bits_for(u32 C)
 	return b;
 }
 
+// ---------------------------------------------------------------------------
+// Asynchronous build (option "async_build"): no read-back, the host never waits.  The counts the reference reads
+// back (total_triangles, frustum_grid.h:254) stay on the device; launches and buffers are sized by what the same
+// grid needed in the previous build plus a margin, and every kernel takes the real counts from device memory.
+// k_build_check compares them with the capacities first: when they do not fit, the build is emptied (nothing is
+// written out of bounds) and a status bit is raised, which the host sees at its next synchronisation
+// (UGRT_EOVERFLOW; the following build of the grid runs synchronously and sizes the buffers exactly).
+// ---------------------------------------------------------------------------
+__global__ void k_build_check(const u32 *__restrict__ scan_last, u32 capRn, u32 capW, unsigned long long capR,
+			      unsigned long long active, u32 *__restrict__ rw, u32 *__restrict__ status,
+			      u32 *__restrict__ report)
+{
+	u32 Rn = scan_last[0], W = scan_last[1];
+	report[0] = Rn; // what the build needed: the next build's estimate
+	report[1] = W;
+	if (Rn > capRn || W > capW || (unsigned long long)Rn + active * W > capR) {
+		atomicOr(status, UGRT_STATUS_BUILD_OVERFLOW);
+		Rn = 0;
+		W = 0;
+	}
+	rw[0] = Rn;
+	rw[1] = W;
+}
+
+static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, int ylo, int yhi)
+{
+	hipStream_t st = ctx->stream;
+	const int gi = (int)(&G - ctx->grid);
+	int rc;
+	G.valid = false;
+	G.C = C;
+	G.F = F;
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SCAN);
+	rc = ugrt_prim_inclusive_scan(ctx, (const u32 *)G.sizes.p, (u32 *)G.scan.p, (size_t)F);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_SCAN);
+	if (rc)
+		return rc;
+	// capacities: the last known need of this grid + a quarter; the wide list goes through the rank kernel
+	const unsigned long long active = (unsigned long long)(C / ((u32)ny * (u32)nz)) * (u32)(yhi - ylo + 1) * (u32)nz;
+	const u32 estRn = G.est_rn, estW = G.est_w;
+	u32 capRn = estRn + estRn / 4u + 65536u, capW = estW + estW / 4u + 16u;
+	if (capW > 4096u)
+		capW = 4096u;
+	unsigned long long capR = (unsigned long long)capRn + active * capW;
+	if (capR > 0xFFFFFFF0ull)
+		capR = 0xFFFFFFF0ull;
+	// never shrink below what the buffers already hold: a grow-only arena
+	if ((size_t)capRn * 4 < G.key[1].cap && G.key[1].cap / 4 < 0xFFFFFFF0ull)
+		capRn = (u32)(G.key[1].cap / 4);
+	if (capR * 4 < G.key[0].cap)
+		capR = G.key[0].cap / 4 < 0xFFFFFFF0ull ? G.key[0].cap / 4 : 0xFFFFFFF0ull;
+	if ((rc = ugrt_buf_reserve(ctx, G.key[0], (size_t)capR * 4)) || (rc = ugrt_buf_reserve(ctx, G.val[0], (size_t)capR * 4)) ||
+	    (rc = ugrt_buf_reserve(ctx, G.key[1], (size_t)capRn * 4)) || (rc = ugrt_buf_reserve(ctx, G.val[1], (size_t)capRn * 4)) ||
+	    (rc = ugrt_buf_reserve(ctx, G.parts, ((size_t)capRn / BUILD_THREADS + 2) * 4)) ||
+	    (rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 8 + 16)) || (rc = ugrt_buf_reserve(ctx, G.offset, (size_t)C * 4)))
+		return rc;
+	// the capacities actually available (buffers may be larger than asked for)
+	capRn = (u32)((G.key[1].cap < G.val[1].cap ? G.key[1].cap : G.val[1].cap) / 4 < 0xFFFFFFF0ull
+			      ? (G.key[1].cap < G.val[1].cap ? G.key[1].cap : G.val[1].cap) / 4 : 0xFFFFFFF0ull);
+	if ((size_t)capRn / BUILD_THREADS + 2 > G.parts.cap / 4)
+		capRn = (u32)((G.parts.cap / 4 - 2) * BUILD_THREADS);
+	capR = (G.key[0].cap < G.val[0].cap ? G.key[0].cap : G.val[0].cap) / 4;
+	if (capR > 0xFFFFFFF0ull)
+		capR = 0xFFFFFFF0ull;
+	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
+	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
+	u32 *rw = ctx->d_small + UGRT_DSMALL_RW + 2 * gi, *status = ctx->d_small + UGRT_DSMALL_STATUS;
+	u32 *report = ctx->d_small + UGRT_DSMALL_REPORT + 2 * gi;
+	hipLaunchKernelGGL(k_build_check, dim3(1), dim3(1), 0, st, (const u32 *)G.scan.p + (F - 1), capRn, capW, capR, active, rw,
+			   status, report);
+	UGRT_HIP(hipGetLastError());
+	WideBox wb;
+	wb.W = 0;
+	wb.ny = (u32)ny;
+	wb.nz = (u32)nz;
+	wb.ylo = (u32)ylo;
+	wb.yhi = (u32)yhi;
+	wb.rw = rw;
+	// launch sizes: the estimate plus the margin (every kernel stops at the real count)
+	const u32 launchRn = estRn + estRn / 4u + 65536u < capRn ? estRn + estRn / 4u + 65536u : capRn;
+	const u32 nparts = (launchRn + BUILD_THREADS - 1) / BUILD_THREADS;
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
+	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, (const u32 *)rw);
+	hipLaunchKernelGGL(k_fill, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)G.scan.p, (const Rng *)G.rng.p,
+			   (const u32 *)G.parts.p, 0u, ny, nz, k0, v0, (u32 *)G.span.p, 2u * C + 1u, (const u32 *)rw);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
+	UGRT_HIP(hipGetLastError());
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
+	rc = ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, launchRn, bits_for(C), rw);
+	if (rc)
+		return rc;
+	hipLaunchKernelGGL(k_wide_rank, dim3((capW + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+			   (const u32 *)wl, 0u, wsorted, (const u32 *)rw);
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
+	UGRT_HIP(hipGetLastError());
+	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
+	u32 *cstart = (u32 *)G.span.p + C, *used = cstart + C;
+	hipLaunchKernelGGL(k_bounds, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, 0u, cstart, (u32 *)G.span.p,
+			   (const u32 *)rw);
+	const u32 span_blocks = (C + BUILD_THREADS - 1) / BUILD_THREADS;
+	hipLaunchKernelGGL(k_span, dim3(span_blocks < 512u ? span_blocks : 512u), dim3(BUILD_THREADS), 0, st,
+			   (const u32 *)cstart, (u32 *)G.span.p, C, used, wb);
+	UGRT_HIP(hipGetLastError());
+	if ((rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C)))
+		return rc;
+	// the merged lists always go to key[0]/val[0] (without wide triangles the narrow merge is a copy)
+	hipLaunchKernelGGL(k_merge_narrow, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, (const u32 *)v1, 0u,
+			   (const u32 *)cstart, (const u32 *)G.offset.p, (const u32 *)wsorted, wb, k0, v0);
+	u32 blocks = C < 256u * 32u ? C : 256u * 32u;
+	hipLaunchKernelGGL(k_merge_wide, dim3(blocks), dim3(64), 0, st, (const u32 *)v1, (const u32 *)cstart,
+			   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0);
+	UGRT_HIP(hipGetLastError());
+	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
+	G.keys = k0;
+	G.vals = v0;
+	G.R = (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
+	G.r_exact = false;
+	G.active_cells = active;
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REPORT + 2 * gi, report, 8, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + gi, used, 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_STATUS, status, 4, hipMemcpyDeviceToHost, st));
+	G.async_pending = true;
+	G.valid = true;
+	return UGRT_OK;
+}
+
 // shared tail of the three builders: sizes/rng/wide list are filled, ny/nz give the key layout,
 // [ylo, yhi] the y range of the cells a wide triangle covers
 static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, int ylo, int yhi)
 {
 	hipStream_t st = ctx->stream;
 	int rc;
+	const int gidx = (int)(&G - ctx->grid);
+	if (G.async_pending) { // what the previous asynchronous build of this grid reported (possibly a frame old)
+		G.est_rn = ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx];
+		G.est_w = ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx + 1];
+	}
+	// asynchronous when asked for, when this grid has been built before (an estimate exists), when no overflow is
+	// pending, and when the wide list fits the rank kernel
+	if (ctx->opt[UGRT_OPT_ASYNC_BUILD] == 1 && G.have_est && G.est_w <= 3000u && ctx->cfg.slabs == 1 &&
+	    ctx->h_pinned[UGRT_PIN_STATUS] == 0u && !ctx->overflow_seen)
+		return build_common_async(ctx, G, F, C, ny, nz, ylo, yhi);
+	if (ctx->h_pinned[UGRT_PIN_STATUS] != 0u)
+		ctx->overflow_seen = true; // reported by ugrt_ctx_synchronize; until then every call waits and sizes exactly
+	G.async_pending = false;
 	G.valid = false;
 	G.C = C;
 	G.F = F;
@@ -593,12 +759,17 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	wb.nz = (u32)nz;
 	wb.ylo = (u32)ylo;
 	wb.yhi = (u32)yhi;
+	wb.rw = nullptr;
 	const unsigned long long active = (unsigned long long)(C / ((u32)ny * (u32)nz)) * (u32)(yhi - ylo + 1) * (u32)nz;
 	const unsigned long long Rtot = (unsigned long long)Rn + active * W;
 	if (Rtot > 0xFFFFFFF0ull)
 		return ugrt_fail(UGRT_ENOMEM, "grid build: %llu references exceed the 32-bit lists", Rtot);
 	const u32 R = (u32)Rtot;
 	G.R = R;
+	G.r_exact = true;
+	G.est_rn = Rn;
+	G.est_w = W;
+	G.have_est = true;
 	// the sort goes key[0] -> key[1]; with wide triangles the merged lists are written back into key[0]
 	size_t rb1 = (size_t)(Rn ? Rn : 1) * 4, rb0 = W ? (size_t)(R ? R : 1) * 4 : rb1;
 	if ((rc = ugrt_buf_reserve(ctx, G.key[0], rb0)) || (rc = ugrt_buf_reserve(ctx, G.val[0], rb0)) ||
@@ -616,9 +787,10 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 		const u32 nparts = (Rn + BUILD_THREADS - 1) / BUILD_THREADS;
 		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p);
+				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p, (const u32 *)nullptr);
 		hipLaunchKernelGGL(k_fill, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)G.scan.p,
-				   (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0, (u32 *)G.span.p, 2u * C + 1u);
+				   (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0, (u32 *)G.span.p, 2u * C + 1u,
+				   (const u32 *)nullptr);
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
@@ -631,7 +803,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
 		if (W <= 4096u) {
 			hipLaunchKernelGGL(k_wide_rank, dim3((W + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
-					   st, (const u32 *)wl, W, wsorted);
+					   st, (const u32 *)wl, W, wsorted, (const u32 *)nullptr);
 			UGRT_HIP(hipGetLastError());
 		} else {
 			// many wide triangles (a tiny grid): radix sort of the ids, the values are not used
@@ -647,7 +819,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	if (R) {
 		if (Rn) {
 			hipLaunchKernelGGL(k_bounds, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
-					   st, (const u32 *)k1, Rn, cstart, (u32 *)G.span.p);
+					   st, (const u32 *)k1, Rn, cstart, (u32 *)G.span.p, (const u32 *)nullptr);
 			UGRT_HIP(hipGetLastError());
 		}
 		const u32 span_blocks = (C + BUILD_THREADS - 1) / BUILD_THREADS;

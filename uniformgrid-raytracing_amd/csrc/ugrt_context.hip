@@ -87,9 +87,13 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 	ctx->cam.H = cfg->height;
 	ctx->cam.nbx = nbx;
 	ctx->cam.nby = nby;
-	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 32 * sizeof(u32), hipHostMallocDefault);
+	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 64 * sizeof(u32), hipHostMallocDefault);
+	if (e == hipSuccess)
+		memset(ctx->h_pinned, 0, 64 * sizeof(u32));
 	if (e == hipSuccess)
 		e = hipMalloc((void **)&ctx->d_small, UGRT_DSMALL_WORDS * sizeof(u32));
+	if (e == hipSuccess)
+		e = hipMemset(ctx->d_small, 0, UGRT_DSMALL_WORDS * sizeof(u32));
 	if (e != hipSuccess) {
 		ugrt_ctx_destroy(ctx);
 		return ugrt_fail(UGRT_EHIP, "ctx_create: %s", hipGetErrorString(e));
@@ -187,6 +191,7 @@ static const struct {
 	{ "primary_seg", 64, 1 << 20 }, { "shadow_beam", 64, 8192 },
 	{ "shadow_xseg", 64, 1 << 20 }, { "shadow_sizebits", 0, 8 },    { "shadow_itemsort", 0, 1 },
 	{ "shadow_mbits", 1, 24 },      { "shadow_key64", 0, 1 },       { "sort_library", 0, 1 },
+	{ "async_build", 0, 1 },
 };
 
 extern "C" int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value)
@@ -219,6 +224,22 @@ extern "C" int ugrt_ctx_synchronize(ugrt_ctx *ctx)
 	if (!ctx)
 		return ugrt_fail(UGRT_EINVAL, "synchronize: null ctx");
 	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	// asynchronous builds / shadow passes: a count that did not fit the capacity it was given (sized by the call
+	// before) left that call's results incomplete.  Reported once; the next build and shadow pass run in the
+	// synchronous form and size the buffers exactly.
+	if (ctx->h_pinned[UGRT_PIN_STATUS] != 0u || ctx->overflow_seen) {
+		const unsigned bits = ctx->h_pinned[UGRT_PIN_STATUS];
+		ctx->overflow_seen = false;
+		ctx->h_pinned[UGRT_PIN_STATUS] = 0u;
+		UGRT_HIP(hipMemsetAsync(ctx->d_small + UGRT_DSMALL_STATUS, 0, 4, ctx->stream));
+		UGRT_HIP(hipStreamSynchronize(ctx->stream));
+		for (int g = 0; g < 3; g++)
+			ctx->grid[g].have_est = false;
+		ctx->have_shadow_est = false;
+		return ugrt_fail(UGRT_EOVERFLOW, "an asynchronous call needed more room than its estimate gave it (status %u: "
+						  "1 grid build, 2 shadow candidate pairs, 4 shadow work items): the frames since the last "
+						  "synchronisation are incomplete, repeat them", bits);
+	}
 	return UGRT_OK;
 }
 
@@ -278,6 +299,9 @@ extern "C" int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out)
 	out->d_span = (unsigned *)G.span.p;
 	out->d_offset = (unsigned *)G.offset.p;
 	out->total_refs = G.R;
+	if (!G.r_exact) // asynchronous build: what the build reported (final once the stream has been synchronised)
+		out->total_refs = (unsigned)(ctx->h_pinned[UGRT_PIN_REPORT + 2 * which] +
+					     G.active_cells * ctx->h_pinned[UGRT_PIN_REPORT + 2 * which + 1]);
 	out->num_cells = G.C;
 	out->cells_used = ctx->h_pinned[4 + which];
 	return UGRT_OK;
@@ -390,6 +414,8 @@ extern "C" int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8])
 		return ugrt_fail(UGRT_EINVAL, "stats_get: null argument");
 	UGRT_HIP(hipStreamSynchronize(ctx->stream));
 	memcpy(stats, ctx->stats, sizeof(ctx->stats));
+	if (ctx->shadow_async_pending)
+		stats[1] = ctx->h_pinned[UGRT_PIN_SHADOW + 1];
 	if (ctx->stats[2]) { // the shadow tracer ran: its work counters were copied to pinned memory
 		memcpy(&stats[6], ctx->h_pinned + 14, 8);
 		memcpy(&stats[7], ctx->h_pinned + 16, 8);

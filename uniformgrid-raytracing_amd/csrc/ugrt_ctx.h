@@ -33,6 +33,7 @@ enum {
 	UGRT_OPT_SHADOW_MBITS,     // "shadow_mbits"
 	UGRT_OPT_SHADOW_KEY64,     // "shadow_key64"
 	UGRT_OPT_SORT_LIBRARY,     // "sort_library": 1 = rocPRIM radix sort instead of the built-in one
+	UGRT_OPT_ASYNC_BUILD,      // "async_build": 1 = grid builds and the shadow tracer never wait for the device
 	UGRT_OPT_COUNT
 };
 
@@ -50,6 +51,10 @@ struct Grid {
 	DevBuf projz;                     // NUM_SLABS > 1: projCoordZ per triangle, then {zMin, zMax} as ordered integers
 	DevBuf uspan;                     // NUM_SLABS > 1: span/offset of a cell's slabs taken together (shadow tracer)
 	int slabs = 1, F = 0;
+	// asynchronous builds: what the grid needed last time (narrow references, wide triangles)
+	u32 est_rn = 0, est_w = 0;
+	bool have_est = false, async_pending = false, r_exact = true;
+	unsigned long long active_cells = 0;
 	u32 *keys = nullptr, *vals = nullptr; // sorted result (one of key[i]/val[i])
 	u32 R = 0, C = 0, cells_used = 0;
 	int dims[3] = { 0, 0, 0 };
@@ -58,11 +63,21 @@ struct Grid {
 };
 
 // layout of ugrt_ctx::d_small (u32 words): [0,32) totals and tracer counters, [32,132) the 5x5x4 direction
-// table, [132, 132 + 64) the DDA's work counters (u64)
+// table, [132, 236) the DDA's work counters (u64), [236, 264) counts of asynchronous builds / shadow passes
 #define UGRT_DSMALL_TICKET 8
+#define UGRT_DSMALL_STATUS 14 // status bits of asynchronous calls
+#define UGRT_DSMALL_RW 236     // [3][2] checked {narrow references, wide triangles} of an asynchronous build
+#define UGRT_DSMALL_REPORT 242 // [3][2] the same as found (what the next build is sized by)
+#define UGRT_DSMALL_SHADOW 248 // [8] asynchronous shadow tracer: checked and reported counts
+#define UGRT_PIN_STATUS 20
+#define UGRT_PIN_REPORT 22
+#define UGRT_PIN_SHADOW 30 // {pairs, beams} of the last asynchronous shadow pass
+#define UGRT_STATUS_BUILD_OVERFLOW 1u
+#define UGRT_STATUS_PAIR_OVERFLOW 2u
+#define UGRT_STATUS_ITEM_OVERFLOW 4u
 #define UGRT_DSMALL_TEX 32
 #define UGRT_DSMALL_DDA 132
-#define UGRT_DSMALL_WORDS (132 + 104)
+#define UGRT_DSMALL_WORDS (132 + 104 + 28)
 #define UGRT_DDA_STATS 46
 
 struct ProfPair {
@@ -106,6 +121,10 @@ struct ugrt_ctx {
 	int opt[UGRT_OPT_COUNT];     // ugrt_ctx_set_option; -1 = the built-in default
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;
+	bool overflow_seen = false; // an asynchronous call exceeded a capacity: reported by ugrt_ctx_synchronize
+	// asynchronous shadow pass: candidate pairs and beams of the last pass
+	u32 est_pairs = 0, est_beams = 0;
+	bool have_shadow_est = false, shadow_async_pending = false;
 	unsigned long long stats[8] = { 0 };
 	unsigned long long dda_stats[UGRT_DDA_STATS] = { 0 }; // ugrt_stats_dda
 };
@@ -131,13 +150,15 @@ void ugrt_prof_end(ugrt_ctx *ctx, int stage);
 int ugrt_prim_inclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
 int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
 // stable LSD radix sort of (key,value) pairs on key bits [0,end_bit)
+// (n_dev != nullptr: the pair count lives on the device and n is the capacity the launches are sized for)
 int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
-			 int end_bit);
+			 int end_bit, const u32 *n_dev = nullptr);
 // the same on the library's onesweep (UGRT_SORT=rocprim, and the reference point of the sort tests)
 int ugrt_prim_sort_pairs_rocprim(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
 				 int end_bit);
 // ugrt_sort.hip
-int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit);
+int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
+			const u32 *n_dev = nullptr);
 int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,
 			   int end_bit);
 

@@ -40,11 +40,11 @@ int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n)
 }
 
 int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
-			 int end_bit)
+			 int end_bit, const u32 *n_dev)
 {
-	if (ctx->opt[UGRT_OPT_SORT_LIBRARY] == 1 || n > ((size_t)1 << 30))
+	if (!n_dev && (ctx->opt[UGRT_OPT_SORT_LIBRARY] == 1 || n > ((size_t)1 << 30)))
 		return ugrt_prim_sort_pairs_rocprim(ctx, kin, kout, vin, vout, n, end_bit);
-	return ugrt_sort_pairs_u32(ctx, kin, kout, vin, vout, n, end_bit);
+	return ugrt_sort_pairs_u32(ctx, kin, kout, vin, vout, n, end_bit, n_dev);
 }
 
 int ugrt_prim_sort_pairs_rocprim(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,

@@ -34,9 +34,12 @@
 #define RS_VALUE 0x7FFFFFFFu
 
 // digit histograms of all passes in one read of the keys
+// (n_dev: the number of pairs when only the device knows it; n is then the capacity the launch was sized for)
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, int passes, u32 end_bit,
-							 u32 *__restrict__ hist)
+							 u32 *__restrict__ hist, const u32 *__restrict__ n_dev)
 {
+	if (n_dev)
+		n = *n_dev < n ? *n_dev : n;
 	__shared__ u32 s_h[RS_MAXPASS][RS_BINS];
 	if (threadIdx.x < RS_BINS)
 		for (int p = 0; p < passes; p++)
@@ -103,8 +106,10 @@ __device__ __forceinline__ u32 d_block_excl_scan(u32 v, u32 *s_part)
 __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
 							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
 							 u32 dmask, const u32 *__restrict__ hist, u32 *look, u32 *look2,
-							 u32 *ticket)
+							 u32 *ticket, const u32 *__restrict__ n_dev)
 {
+	if (n_dev)
+		n = *n_dev < n ? *n_dev : n;
 	__shared__ u32 s_keys[RS_TILE], s_vals[RS_TILE];
 	__shared__ u32 s_cnt[RS_WAVES][RS_BINS]; // per wave: digit counters while ranking, then the wave's offset inside the digit
 	__shared__ u32 s_lstart[RS_BINS]; // first slot of the digit inside the sorted tile
@@ -119,6 +124,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 	__syncthreads();
 	const u32 tile = s_tile;
 	const u32 base = tile * RS_TILE;
+	if (base >= n)
+		return; // a launch sized by the capacity: this tile holds nothing, and no tile waits for a later one
 	u32 k[RS_ITEMS], r[RS_ITEMS];
 #pragma unroll
 	for (int i = 0; i < RS_ITEMS; i++) {
@@ -243,7 +250,8 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 }
 
 // stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
-int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit)
+int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
+			const u32 *n_dev)
 {
 	if (n == 0)
 		return UGRT_OK;
@@ -272,7 +280,7 @@ int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin
 	UGRT_HIP(hipMemsetAsync(hist, 0, words * 4, st));
 	u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
 	hblocks = hblocks > 256u ? 256u : hblocks;
-	hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, passes, (u32)end_bit, hist);
+	hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, passes, (u32)end_bit, hist, n_dev);
 	UGRT_HIP(hipGetLastError());
 	const u32 *ki = kin, *vi = vin;
 	for (int p = 0; p < passes; p++) {
@@ -282,7 +290,7 @@ int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin
 		const u32 bits = (u32)(end_bit - 8 * p) < 8u ? (u32)(end_bit - 8 * p) : 8u;
 		hipLaunchKernelGGL(k_rs_pass, dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),
 				   (1u << bits) - 1u, (const u32 *)(hist + (size_t)p * RS_BINS),
-				   look + (size_t)p * per_pass, look + (size_t)p * per_pass + (size_t)tiles * RS_BINS, ticket + p);
+				   look + (size_t)p * per_pass, look + (size_t)p * per_pass + (size_t)tiles * RS_BINS, ticket + p, n_dev);
 		UGRT_HIP(hipGetLastError());
 		ki = ko;
 		vi = vo;

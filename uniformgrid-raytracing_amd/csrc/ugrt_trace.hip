@@ -917,17 +917,36 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 		d_flush_pairs(buf_beam, buf_tri, nbuf, lane, pair_count, pair_cap, pair_beam, pair_tri);
 }
 
+// (pg: {candidate pairs, beams} on the device when the host does not know them - the asynchronous form; the launch
+// is then sized by an estimate and strides)
 __global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict__ beam, u32 P, u32 sbits,
-							   u32 *__restrict__ pstart, u32 *__restrict__ pend)
+							   u32 *__restrict__ pstart, u32 *__restrict__ pend,
+							   const u32 *__restrict__ pg)
 {
-	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (i >= P)
-		return;
-	u32 b = beam[i] >> sbits;
-	if (i == 0 || (beam[i - 1] >> sbits) != b)
-		pstart[b] = i;
-	if (i == P - 1 || (beam[i + 1] >> sbits) != b)
-		pend[b] = i + 1;
+	if (pg)
+		P = pg[0];
+	for (u32 i = blockIdx.x * WL_THREADS + threadIdx.x; i < P; i += gridDim.x * WL_THREADS) {
+		u32 b = beam[i] >> sbits;
+		if (i == 0 || (beam[i - 1] >> sbits) != b)
+			pstart[b] = i;
+		if (i == P - 1 || (beam[i + 1] >> sbits) != b)
+			pend[b] = i + 1;
+	}
+}
+
+// asynchronous shadow pass: the counts of the cull pass against the capacities the later launches were sized for
+__global__ void k_pair_check(const u32 *__restrict__ pcount, u32 cap, const u32 *__restrict__ gcount, u32 gbound,
+			     u32 *__restrict__ pg, u32 *__restrict__ status, u32 *__restrict__ report)
+{
+	u32 P = *pcount, G = *gcount;
+	report[0] = P;
+	report[1] = G;
+	if (P > cap || G > gbound) {
+		atomicOr(status, UGRT_STATUS_PAIR_OVERFLOW);
+		P = 0; // nothing is traced: the frame is reported as incomplete
+	}
+	pg[0] = P;
+	pg[1] = G;
 }
 
 
@@ -936,15 +955,20 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict_
 #define XSEG_LAST 254u
 __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
 								 const GBox *__restrict__ boxes, u32 G, u32 *__restrict__ xcnt,
-								 unsigned long long *__restrict__ staged, u32 XSEG)
+								 unsigned long long *__restrict__ staged, u32 XSEG,
+								 const u32 *__restrict__ pg, u32 Gcap)
 {
 	u32 g = blockIdx.x * WL_THREADS + threadIdx.x;
 	unsigned long long mine = 0;
+	if (pg)
+		G = pg[0] ? pg[1] : 0u; // (no pairs: no items)
 	if (g < G) {
 		const u32 cand = pend[g] - pstart[g], nsub = (boxes[g].ray_count + 63u) / 64u;
 		const u32 nseg = (cand + XSEG - 1) / XSEG;
 		xcnt[g] = (nseg < XSEG_LAST + 1u ? nseg : XSEG_LAST + 1u) * nsub;
 		mine = (unsigned long long)cand * nsub;
+	} else if (g < Gcap) {
+		xcnt[g] = 0; // the scan runs over the capacity
 	}
 	// candidates staged by the exact pass (work accounting): one atomic per wave
 #pragma unroll
@@ -961,9 +985,12 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__res
 __global__ __launch_bounds__(WL_THREADS) void k_pair_items(const u32 *__restrict__ xincl, u32 G, u32 cap,
 							    const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
 							    const GBox *__restrict__ boxes, u32 XSEG,
-							    u32 *__restrict__ item_seg, u32 *__restrict__ item_sub)
+							    u32 *__restrict__ item_seg, u32 *__restrict__ item_sub,
+							    u32 *__restrict__ status)
 {
 	u32 it = blockIdx.x * WL_THREADS + threadIdx.x;
+	if (status && it == 0 && xincl[G - 1] > cap)
+		atomicOr(status, UGRT_STATUS_ITEM_OVERFLOW); // asynchronous form: the list was sized by an estimate
 	if (it >= cap)
 		return;
 	if (it >= xincl[G - 1]) { // the list is sorted at its capacity: padding goes last
@@ -991,11 +1018,13 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      const float *__restrict__ ray_direction_list,
 						      int *__restrict__ is_shadowed, const u32 *__restrict__ ray_pixels,
 						      const float *__restrict__ cmPt, u32 XSEG, u32 *__restrict__ sub_done,
-						      u32 nsubmax, const float4 *__restrict__ sray)
+						      u32 nsubmax, const float4 *__restrict__ sray, u32 item_cap)
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
 	const int lane = threadIdx.x;
-	const u32 total = xincl[G - 1];
+	u32 total = xincl[G - 1];
+	if (total > item_cap)
+		total = item_cap; // (asynchronous form: a list cut at its estimated capacity is flagged by k_pair_items)
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
 	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
 		const u32 sgm = item_seg[it], gs = item_sub[it];
@@ -1237,16 +1266,31 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	u32 sbits = ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] >= 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] : 4u;
 	sbits = sbits > 8u ? 8u : sbits;
-	// 2. cull pass -> (beam, triangle) candidate pairs; grows the pair buffer and repeats if it was too small
+	// 2. cull pass -> (beam, triangle) candidate pairs.  Synchronous form: the pair count is read back (it sizes the
+	// launches that follow), and the pass is repeated with a larger buffer if it was too small.  Asynchronous form
+	// (option "async_build", once a synchronous pass has left estimates): no read-back; the launches are sized by
+	// the previous pass's counts plus a quarter, the kernels take the real counts from the device, and counts
+	// beyond the capacities raise a status bit instead (UGRT_EOVERFLOW at the next synchronisation).
 	u32 *pcount = ctx->d_small + 20; // right behind the work counters: cleared with them
-	u32 P = 0;
+	u32 *status = ctx->d_small + UGRT_DSMALL_STATUS, *pg = ctx->d_small + UGRT_DSMALL_SHADOW, *report = pg + 2;
+	if (ctx->shadow_async_pending) { // what the last asynchronous pass needed (possibly a frame old)
+		ctx->est_pairs = ctx->h_pinned[UGRT_PIN_SHADOW];
+		ctx->est_beams = ctx->h_pinned[UGRT_PIN_SHADOW + 1];
+	}
+	const bool async = ctx->opt[UGRT_OPT_ASYNC_BUILD] == 1 && ctx->have_shadow_est && ctx->h_pinned[UGRT_PIN_STATUS] == 0u &&
+			   !ctx->overflow_seen;
+	if (!async && ctx->h_pinned[UGRT_PIN_STATUS] != 0u)
+		ctx->overflow_seen = true;
+	u32 P = 0, G = 0, Gcap = 0, xcap = 0;
+	const u32 *pgp = nullptr; // device counts (asynchronous form)
 	for (int attempt = 0; attempt < 3; attempt++) {
 		size_t cap = ctx->tkey[0].cap / 4;
-		if (cap < (size_t)1 << 22) {
-			if ((rc = ugrt_buf_reserve(ctx, ctx->tkey[0], (size_t)4 << 22)) ||
-			    (rc = ugrt_buf_reserve(ctx, ctx->tkey[1], (size_t)4 << 22)) ||
-			    (rc = ugrt_buf_reserve(ctx, ctx->tval[0], (size_t)4 << 22)) ||
-			    (rc = ugrt_buf_reserve(ctx, ctx->tval[1], (size_t)4 << 22)))
+		size_t want0 = (size_t)4 << 22;
+		if (async && ((size_t)ctx->est_pairs + ctx->est_pairs / 2 + 65536) * 4 > want0)
+			want0 = ((size_t)ctx->est_pairs + ctx->est_pairs / 2 + 65536) * 4;
+		if (cap * 4 < want0) {
+			if ((rc = ugrt_buf_reserve(ctx, ctx->tkey[0], want0)) || (rc = ugrt_buf_reserve(ctx, ctx->tkey[1], want0)) ||
+			    (rc = ugrt_buf_reserve(ctx, ctx->tval[0], want0)) || (rc = ugrt_buf_reserve(ctx, ctx->tval[1], want0)))
 				return rc;
 		}
 		cap = ctx->tkey[0].cap / 4;
@@ -1273,6 +1317,24 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 					   (const u32 *)ctx->citem.p);
 		ugrt_prof_end(ctx, UGRT_ST_SHADOW_CULL);
 		UGRT_HIP(hipGetLastError());
+		if (async) {
+			// beams: a power of two above the estimate keeps the sort at the key width the real count needs
+			u32 gb = 1;
+			while (gb < ctx->est_beams + ctx->est_beams / 4u + 1u)
+				gb <<= 1;
+			Gcap = (u32)maxg;
+			G = gb < Gcap ? gb : Gcap; // only its bit width is used below
+			hipLaunchKernelGGL(k_pair_check, dim3(1), dim3(1), 0, st, (const u32 *)pcount, (u32)cap,
+					   (const u32 *)(gincl + (C - 1)), G, pg, status, report);
+			UGRT_HIP(hipGetLastError());
+			UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW, report, 8, hipMemcpyDeviceToHost, st));
+			pgp = pg;
+			const size_t lp = (size_t)ctx->est_pairs + ctx->est_pairs / 4 + 65536;
+			P = (u32)(lp < cap ? lp : cap); // launch size of the per-pair kernels
+			xcap = (ctx->est_beams + ctx->est_beams / 4u + 64u + P / XSEG) * (beam / 64u);
+			ctx->shadow_async_pending = true;
+			break;
+		}
 		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, pcount, 4, hipMemcpyDeviceToHost, st));
 		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 12, gincl + (C - 1), 4, hipMemcpyDeviceToHost, st));
 		UGRT_HIP(hipStreamSynchronize(st));
@@ -1286,31 +1348,41 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		    (rc = ugrt_buf_reserve(ctx, ctx->tval[0], want)) || (rc = ugrt_buf_reserve(ctx, ctx->tval[1], want)))
 			return rc;
 	}
-	const u32 G = ctx->h_pinned[12];
-	ctx->stats[1] = G;
-	if (P == 0 || G == 0)
-		return UGRT_OK;
+	if (!async) {
+		G = ctx->h_pinned[12];
+		Gcap = G;
+		ctx->stats[1] = G;
+		ctx->est_pairs = P;
+		ctx->est_beams = G;
+		ctx->have_shadow_est = true;
+		ctx->shadow_async_pending = false;
+		if (P == 0 || G == 0)
+			return UGRT_OK;
+		xcap = (G + P / XSEG) * (beam / 64u); // >= number of exact-pass items
+	}
 	// 3. candidates by beam
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	if ((rc = ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
-				       (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits)))
+				       (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)))
 		return rc;
-	hipLaunchKernelGGL(k_pair_runs, dim3((P + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)ctx->tkey[1].p, P, sbits, pstart, pend);
+	{
+		u32 pb = (P + WL_THREADS - 1) / WL_THREADS;
+		hipLaunchKernelGGL(k_pair_runs, dim3(pb ? pb : 1u), dim3(WL_THREADS), 0, st, (const u32 *)ctx->tkey[1].p, P, sbits,
+				   pstart, pend, pgp);
+	}
 	UGRT_HIP(hipGetLastError());
-	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + G;
-	hipLaunchKernelGGL(k_pair_item_count, dim3((G + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt, wcnt + 1, XSEG);
+	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + Gcap;
+	hipLaunchKernelGGL(k_pair_item_count, dim3((Gcap + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
+			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt, wcnt + 1, XSEG, pgp, Gcap);
 	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, G)))
+	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, Gcap)))
 		return rc;
-	const u32 xcap = (G + P / XSEG) * (beam / 64u); // >= number of exact-pass items
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sitem, (size_t)xcap * 16)))
 		return rc;
 	u32 *iseg0 = (u32 *)ctx->sitem.p, *isub0 = iseg0 + xcap, *iseg1 = isub0 + xcap, *isub1 = iseg1 + xcap;
 	hipLaunchKernelGGL(k_pair_items, dim3((xcap + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)xincl, G, xcap, (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, XSEG,
-			   iseg0, isub0);
+			   (const u32 *)xincl, Gcap, xcap, (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, XSEG,
+			   iseg0, isub0, async ? status : (u32 *)nullptr);
 	UGRT_HIP(hipGetLastError());
 	const bool item_sort = ctx->opt[UGRT_OPT_SHADOW_ITEMSORT] != 0;
 	if (item_sort) {
@@ -1321,21 +1393,23 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		isub1 = isub0;
 	}
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 14, wcnt, 16, hipMemcpyDeviceToHost, st)); // read by ugrt_stats_get
+	if (async)
+		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_STATUS, status, 4, hipMemcpyDeviceToHost, st));
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	if (use_rec)
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
-				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
+				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p);
+				   (const float4 *)ctx->sray.p, xcap);
 	else
 		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
-				   (const u32 *)xincl, G, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
+				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p);
+				   (const float4 *)ctx->sray.p, xcap);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;

@@ -251,13 +251,14 @@ def main():
     shards = parallel.GridShards(dist, torch, ctx.device, rank, world, host_staging=rehearse) \
         if args.shard_builds else None
     r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
-                      overlap=not args.no_overlap and shards is None, shards=shards)
+                      overlap=not args.no_overlap and shards is None, shards=shards, helper_thread=args.waiting_builds)
     renderers = [r]
     for i in range(1, max(1, args.frames_in_flight)):
         with torch.cuda.stream(torch.cuda.Stream(ctx.device)):
             cx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
             renderers.append(ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
-                                           overlap=not args.no_overlap and shards is None, shards=shards))
+                                           overlap=not args.no_overlap and shards is None, shards=shards,
+                                           helper_thread=args.waiting_builds))
             renderers[-1]._stream = torch.cuda.current_stream(ctx.device)
     opts = ([] if args.waiting_builds else ["async_build=1"]) + args.opt
     for kv in opts:

@@ -6,7 +6,8 @@
 // check_for_shadows }, simpleShade | spotlight_shade, add_shadows, writePPM.  GLUT, the PBO and the ImageMagick shell
 // calls are gone; resolution and cameras come from a parameter file instead of main.cu.h / the source text.
 // `streams 2` runs the same frame on two contexts and two HIP streams from this ONE host thread (light grid on the
-// side stream beside the camera pass), `reflect 1` adds the bounce (uniform grid + 3D-DDA).
+// side stream beside the camera pass; the builds do not wait for the device: option async_build), `reflect 1` adds
+// the bounce (uniform grid + 3D-DDA).
 //
 //   display_main PARAMS OUT.ppm        PARAMS: lines "key v0 v1 ..." (see read_params)
 #include <hip/hip_runtime.h>
@@ -240,6 +241,9 @@ int main(int argc, char **argv)
 		UGRT_CHECK(ugrt_ctx_create(&g_aux, 0, &cfg));
 		HIP_CHECK(hipStreamCreate(&g_side));
 		UGRT_CHECK(ugrt_ctx_set_stream(g_aux, g_side));
+		// builds that never wait for the device: this one host thread keeps both streams fed
+		UGRT_CHECK(ugrt_ctx_set_option(g_ctx, "async_build", 1));
+		UGRT_CHECK(ugrt_ctx_set_option(g_aux, "async_build", 1));
 		HIP_CHECK(hipEventCreateWithFlags(&ev_geometry, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ev_primary, hipEventDisableTiming));
 		HIP_CHECK(hipEventCreateWithFlags(&ev_light_grid, hipEventDisableTiming));
@@ -279,7 +283,9 @@ int main(int argc, char **argv)
 	for (int f = 0; f < P.frames; f++)
 		display();
 	HIP_CHECK(hipMemcpyAsync(h_image, d_image, 3 * N, hipMemcpyDeviceToHost, g_main)); // main.cu:244
-	HIP_CHECK(hipStreamSynchronize(g_main));
+	UGRT_CHECK(ugrt_ctx_synchronize(g_ctx)); // (reports an asynchronous build that outgrew its estimate)
+	if (g_aux)
+		UGRT_CHECK(ugrt_ctx_synchronize(g_aux));
 	writePPM(argv[2]);
 	printf("frames %d streams %d chunks %zu\n", frame_cnt, P.streams, *dData->h_numCudaBlocks);
 	return 0;

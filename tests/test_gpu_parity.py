@@ -701,8 +701,11 @@ def test_gather_path_without_records(ugrt, O, torch):
     np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
 
 
-def test_overlapped_display_equals_sequential(ugrt, O, torch):
-    """Renderer(overlap=True) builds the light and uniform grids on a second stream/context; same frame."""
+@pytest.mark.parametrize("helper_thread", [True, False])
+def test_overlapped_display_equals_sequential(ugrt, O, torch, helper_thread):
+    """Renderer(overlap=True) builds the light and uniform grids on a second stream/context; same frame.  With a
+    helper thread for the side stream (builds that wait for the device), or from one thread with builds that never
+    wait (option async_build)."""
     s = scene(ugrt, "crash")
     W, H, lg, ud = 256, 144, (64, 64), (32, 32, 16)
     setup = setup_for(ugrt, s, "ref")
@@ -710,8 +713,9 @@ def test_overlapped_display_equals_sequential(ugrt, O, torch):
     r.display(setup, shadows=True, reflect=True)
     ctx.synchronize()
     ctx2 = ugrt.Context(W, H, light_grid=lg, uniform_dims=ud)
-    r2 = ugrt.Renderer(ctx2, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True)
-    for _ in range(3):  # several frames: the streams must stay ordered across frames
+    r2 = ugrt.Renderer(ctx2, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True,
+                       helper_thread=helper_thread)
+    for _ in range(4):  # several frames: the streams must stay ordered across frames
         r2.display(setup, shadows=True, reflect=True)
     r2.synchronize()
     torch.cuda.synchronize()
@@ -720,6 +724,7 @@ def test_overlapped_display_equals_sequential(ugrt, O, torch):
         np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8), err_msg=name)
     want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud)
     np.testing.assert_array_equal(r2.image.cpu().numpy(), want["image"])
+    r2.close()
 
 
 @pytest.mark.parametrize("name,cam,W,H,lg", [("hall", "ref", 256, 256, (64, 64)), ("crash", "ref", 256, 144, (128, 128)),

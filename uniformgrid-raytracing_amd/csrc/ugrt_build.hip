@@ -770,6 +770,9 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	G.est_rn = Rn;
 	G.est_w = W;
 	G.have_est = true;
+	// (the slots an asynchronous build reports into: never older than this build)
+	ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx] = Rn;
+	ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx + 1] = W;
 	// the sort goes key[0] -> key[1]; with wide triangles the merged lists are written back into key[0]
 	size_t rb1 = (size_t)(Rn ? Rn : 1) * 4, rb0 = W ? (size_t)(R ? R : 1) * 4 : rb1;
 	if ((rc = ugrt_buf_reserve(ctx, G.key[0], rb0)) || (rc = ugrt_buf_reserve(ctx, G.val[0], rb0)) ||

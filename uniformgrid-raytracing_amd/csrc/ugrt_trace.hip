@@ -1355,6 +1355,9 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		ctx->est_pairs = P;
 		ctx->est_beams = G;
 		ctx->have_shadow_est = true;
+		// (the slots the asynchronous form reports into: never older than this pass)
+		ctx->h_pinned[UGRT_PIN_SHADOW] = P;
+		ctx->h_pinned[UGRT_PIN_SHADOW + 1] = G;
 		ctx->shadow_async_pending = false;
 		if (P == 0 || G == 0)
 			return UGRT_OK;

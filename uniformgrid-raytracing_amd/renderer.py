@@ -44,7 +44,7 @@ def make_camera(params, fovy, aspect):
 
 class Renderer:
     def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False,
-                 shards=None):
+                 shards=None, helper_thread=True):
         """overlap=True: the light grid and the uniform grid (which do not depend on the camera pass) are built
         by a second context on a second HIP stream while the main stream builds the perspective grid and
         traces the primary rays; streams are joined with events before the grids are consumed.  Same results.
@@ -68,6 +68,11 @@ class Renderer:
                                    rows=ctx.rows, flags=int(ctx.cfg.flags),
                                    uniform_dims=tuple(ctx.cfg.uniform_dims[k] for k in range(3)),
                                    slabs=int(ctx.cfg.slabs))
+            self._inline = not helper_thread
+            if self._inline:
+                # builds that never wait for the device (option async_build): one host thread keeps both streams fed
+                ctx.set_option("async_build", 1)
+                self.aux.set_option("async_build", 1)
             # the bounce runs beside the ray sort and the shadow pass and has slack: four persistent waves per CU leave
             # the registers and LDS of every CU to the main stream's workgroups (with the whole chip taken by
             # the bounce's waves, a sort pass of the main stream waited 0.2 ms for room)
@@ -76,6 +81,8 @@ class Renderer:
             import queue
             import threading
 
+            if self._inline:
+                return self._finish_init(ctx, verts, faces, matidx, mat_list, reflect, reflect_eps)
             self._jobs, self._done = queue.Queue(), queue.Queue()
 
             def loop():
@@ -91,6 +98,10 @@ class Renderer:
 
             self._worker = threading.Thread(target=loop, name="ugrt-aux", daemon=True)
             self._worker.start()
+        self._finish_init(ctx, verts, faces, matidx, mat_list, reflect, reflect_eps)
+
+    def _finish_init(self, ctx, verts, faces, matidx, mat_list, reflect, reflect_eps):
+        t = ctx.torch
         self.F = int(len(faces))
         self.num_materials = int(len(mat_list) // 6 if np.ndim(mat_list) == 1 else len(mat_list))
         self.d_verts = ctx.upload(np.asarray(verts, np.float32).reshape(-1))
@@ -174,6 +185,8 @@ class Renderer:
 
     def display(self, setup, frame_cnt=1, shadows=True, reflect=False, shade=True):
         if self.aux is not None and shade:
+            if getattr(self, "_inline", False):
+                return self._display_two_streams_inline(setup, frame_cnt, shadows, reflect)
             return self._display_overlapped(setup, frame_cnt, shadows, reflect)
         ctx = self.ctx
         t = ctx.torch
@@ -314,6 +327,61 @@ class Renderer:
             raise failed
         if err is not None:
             raise err
+        if reflect:
+            ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                              self.d_matidx, self.d_matlist, self.d_reflect, self.num_materials, self.d_verts,
+                              self.d_faces, self.rays, self.active, self.hit_t, self.hit_id)
+        elif frame_cnt < 2:
+            ctx.shade_simple(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                             self.d_matidx, self.d_matlist, self.num_materials)
+        else:
+            ctx.shade_spotlight(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
+                                self.d_matidx, self.d_matlist, self.num_materials)
+        if shadows:
+            ctx.shade_add_shadows(self.image, self.is_shadowed)
+
+    def _display_two_streams_inline(self, setup, frame_cnt, shadows, reflect):
+        """The two-stream frame from ONE host thread: with option async_build no call waits for the device, so the
+        side stream's work is simply enqueued first (light grid, uniform grid), then the camera pass on the main
+        stream, then what depends on the primary hits on either stream; events join them as in _display_overlapped."""
+        ctx, aux, t = self.ctx, self.aux, self.ctx.torch
+        main, side = self.main_stream, self.aux_stream
+        lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
+        if reflect:
+            self._ensure_reflect_buffers()
+        ev_primary, ev_light_grid = t.cuda.Event(), t.cuda.Event()
+        side.wait_stream(main)  # the geometry of this frame is final on the main stream
+        if shadows:
+            aux.upload_camera(lcam.camcoords)
+            aux.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
+            ev_light_grid.record(side)
+        if reflect:
+            aux.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
+        ctx.set_light_position(setup.shading_light)
+        cam = make_camera(setup.camera, setup.fovy, self.aspect)
+        self._upload_cam_pos(cam.worldori)
+        ctx.upload_camera(cam.camcoords)
+        ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
+        value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
+        ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed, self.intersect_id,
+                          self.d_verts, self.d_faces)
+        ev_primary.record(main)
+        if reflect:
+            side.wait_event(ev_primary)
+            aux.reflect_rays(self.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
+                             self.num_materials, self.d_verts, self.d_faces, self.reflect_eps, self.rays, self.active)
+            uvalue, uspan, uoffset, _ = aux.grid_ptrs(GRID_UNIFORM)
+            aux.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active, self.hit_t,
+                          self.hit_id)
+        ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
+        if shadows:
+            ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
+            self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
+            main.wait_event(ev_light_grid)
+            lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
+            ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
+                             self.d_map, self.prefix, self.cam_pos, self._num_chunks)
+        main.wait_stream(side)
         if reflect:
             ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
                               self.d_matidx, self.d_matlist, self.d_reflect, self.num_materials, self.d_verts,

@@ -255,7 +255,19 @@ __global__ void k_store_table(TexArg t, float *dst)
 		dst[i] = t.v[i];
 }
 
-float *ugrt_ctx_tex(ugrt_ctx *ctx) { return (float *)(ctx->d_small + UGRT_DSMALL_TEX); }
+// device copy of the direction table of the current camera; written (in stream order) when a tracer first asks for
+// it: the light's camera block is uploaded every frame too, but only the camera pass samples the table
+float *ugrt_ctx_tex(ugrt_ctx *ctx)
+{
+	float *dst = (float *)(ctx->d_small + UGRT_DSMALL_TEX);
+	if (ctx->tex_dirty) {
+		TexArg t;
+		memcpy(t.v, ctx->tex_host, sizeof(t.v));
+		hipLaunchKernelGGL(k_store_table, dim3(1), dim3(128), 0, ctx->stream, t, dst);
+		ctx->tex_dirty = false;
+	}
+	return dst;
+}
 
 // per_frame_funcs.h:18-43 fillCoordinatesData (+ setDirectionTexture :161)
 extern "C" int ugrt_upload_camera(ugrt_ctx *ctx, const float camcoords[64])
@@ -263,13 +275,10 @@ extern "C" int ugrt_upload_camera(ugrt_ctx *ctx, const float camcoords[64])
 	if (!ctx || !camcoords)
 		return ugrt_fail(UGRT_EINVAL, "upload_camera: null argument");
 	memcpy(ctx->cam.cc, camcoords, sizeof(float) * 64);
-	TexArg t;
-	int rc = ugrt_camera_direction_table(camcoords, t.v);
+	int rc = ugrt_camera_direction_table(camcoords, ctx->tex_host);
 	if (rc)
 		return rc;
-	UGRT_HIP(hipSetDevice(ctx->device));
-	hipLaunchKernelGGL(k_store_table, dim3(1), dim3(128), 0, ctx->stream, t, ugrt_ctx_tex(ctx));
-	UGRT_HIP(hipGetLastError());
+	ctx->tex_dirty = true; // stored on the device by the next primary trace (ugrt_ctx_tex)
 	return UGRT_OK;
 }
 

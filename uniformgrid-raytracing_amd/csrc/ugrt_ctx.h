@@ -89,6 +89,8 @@ struct ugrt_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	CamBlock cam;
+	float tex_host[100]; // 5x5x4 direction table of the current camera (setDirectionTexture)
+	bool tex_dirty = false;
 	int nbx = 0, nby = 0; // screen grid
 	int face_lo = 0, face_hi = 0; // ugrt_ctx_set_face_window: triangles the light / uniform builds bin (hi 0 = all)
 	int p0 = 0, npix = 0; // first pixel and pixel count of this context's band

@@ -134,11 +134,21 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 		return rc;
 	u32 *tmp = (u32 *)ctx->rmap[0].p;
 	ugrt_prof_begin(ctx, UGRT_ST_SORT_RAYS);
-	// cudppSort(sortPlan, &d_map[IMAGE_SIZE], &d_map[0], 15, IMAGE_SIZE), decision_data.h:177
-	rc = ugrt_prim_sort_pairs(ctx, d_map + n, tmp + n, d_map, tmp, n, key_bits(ncell));
-	if (rc)
-		return rc;
-	UGRT_HIP(hipMemcpyAsync(d_map, tmp, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+	// cudppSort(sortPlan, &d_map[IMAGE_SIZE], &d_map[0], 15, IMAGE_SIZE), decision_data.h:177: in place.  With an even
+	// number of passes the built-in sort reads its input in the first pass only (and in the histogram kernel before
+	// it), writes its own buffers there, and may write the caller's arrays in its last pass; otherwise sort into a
+	// copy and copy back.
+	const int kb = key_bits(ncell);
+	if (((kb + 7) / 8) % 2 == 0 && ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1 && n <= (1u << 30)) {
+		rc = ugrt_sort_pairs_u32(ctx, d_map + n, d_map + n, d_map, d_map, n, kb);
+		if (rc)
+			return rc;
+	} else {
+		rc = ugrt_prim_sort_pairs(ctx, d_map + n, tmp + n, d_map, tmp, n, kb);
+		if (rc)
+			return rc;
+		UGRT_HIP(hipMemcpyAsync(d_map, tmp, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+	}
 	u32 *rstart = (u32 *)ctx->rstart.p, *rend = rstart + ncell;
 	UGRT_HIP(hipMemsetAsync(rstart, 0, (size_t)ncell * 8, st));
 	hipLaunchKernelGGL(k_ray_runs, dim3((n + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,

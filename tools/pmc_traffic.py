@@ -95,7 +95,8 @@ def main():
         if a.get("TCC_HIT_sum") is not None:
             tot = a["TCC_HIT_sum"] + a.get("TCC_MISS_sum", 0.0)
             a["l2_hit_rate"] = round(a["TCC_HIT_sum"] / tot, 3) if tot else None
-        sqrows[k] = {n: (round(v, 1) if isinstance(v, float) else v) for n, v in a.items()}
+        sqrows[k] = {n: (round(v, 3 if (n.startswith('share_') or n == 'l2_hit_rate') else 1) if isinstance(v, float) else v)
+                     for n, v in a.items()}
     json.dump({"note": "rocprofv3 --pmc, per-launch averages over the frames of bench.py --steps 3 --warmup 1; "
                        "SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles summed over the waves; "
                        "issuing + waiting + issue-stalled ~ 1", "build": tag, "kernel_source_hash": h,

@@ -8,7 +8,7 @@ ctx = ugrt.Context(1920, 1080, light_grid=(128, 128), flags=ugrt.FLAG_SHADOW_ALL
 r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
 ref = None
 for beam in (64, 512, 768, 1024, 1536, 2048, 4096):
-    os.environ["UGRT_SHADOW_BEAM"] = str(beam)
+    ctx.set_option("shadow_beam", beam)
     for _ in range(2):
         r.display(setup, reflect=True)
     ctx.synchronize()

@@ -1,6 +1,6 @@
-"""Sweep one of the shadow tracer's environment tunables on the bench workload.
+"""Sweep one of the shadow tracer's options (ugrt_ctx_set_option) on the bench workload.
 
-    python tools/env_sweep.py UGRT_SHADOW_MBITS 2 3 4 5
+    python tools/env_sweep.py shadow_mbits 12 16 17
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["re
 ref = None
 st = ("trace_shadow", "shadow_prep", "shadow_cull")
 for v in vals:
-    os.environ[var] = v
+    ctx.set_option(var, int(v))
     for _ in range(2):
         r.display(setup, reflect=True)
     ctx.synchronize()

@@ -8,7 +8,7 @@ ctx = ugrt.Context(1920, 1080, light_grid=(128, 128), flags=ugrt.FLAG_SHADOW_ALL
 r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
 ref = None
 for seg in (256, 512, 1024, 2048, 4096, 16384):
-    os.environ["UGRT_PRIMARY_SEG"] = str(seg)
+    ctx.set_option("primary_seg", seg)
     for _ in range(2):
         r.display(setup, reflect=True)
     ctx.synchronize()

@@ -195,6 +195,12 @@ def main():
     ap.add_argument("--shard-builds", action="store_true",
                     help="the light grid and the uniform grid are built in N shards of the triangle list, exchanged "
                          "and merged (SURVEY 8f.1; one-stream frame)")
+    ap.add_argument("--no-static-geometry", action="store_true",
+                    help="rebuild the per-triangle records in every grid build, as a caller that rewrites the vertex array "
+                         "behind the library's back must (default: UGRT_FLAG_STATIC_GEOMETRY, the renderer is the only writer)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region rank 0 renders the whole frame on one context and compares it with the "
+                         "gathered image of the last step (byte for byte)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="launch-shape option for every context (ugrt_ctx_set_option), e.g. dda_kernel=1")
     ap.add_argument("--animate", action="store_true",
@@ -246,7 +252,7 @@ def main():
     s = load_scene(ugrt, args.workload, args.scale, rank)
     setup = ugrt.FrameSetup.from_scene(s)
     # the renderer is the only writer of the vertex array (ugrt_animate): triangle records survive between builds
-    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | (0 if args.no_static_geometry else ugrt.FLAG_STATIC_GEOMETRY)
     ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
     shards = parallel.GridShards(dist, torch, ctx.device, rank, world, host_staging=rehearse) \
         if args.shard_builds else None
@@ -283,11 +289,12 @@ def main():
             rr.rotate_bunny(1.81 + 0.05 * frame_no[0])
             frame_no[0] += 1
         if getattr(rr, "_stream", None) is not None:
-            with torch.cuda.stream(rr._stream):
+            with torch.cuda.stream(rr._stream):  # the gather reads the band on the stream that rendered it
                 rr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+                gather.gather(rr.image)
         else:
             rr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
-        gather.gather(rr.image)
+            gather.gather(rr.image)
 
     for _ in range(max(1, args.warmup)):
         step()
@@ -386,6 +393,28 @@ def main():
     for c in profiled:
         c.prof_enable(False)
 
+    verified = None
+    if args.verify:
+        # one more step, gathered synchronously, against the same frame rendered whole by one context
+        last = renderers[turn[0] % len(renderers)]
+        step()
+        gather.finish()
+        for rr in renderers:
+            rr.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            fctx = ugrt.Context(W, H, device=local, light_grid=lg, flags=flags, uniform_dims=udims)
+            fr = ugrt.Renderer(fctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+            fr.d_verts.copy_(last.d_verts)
+            fctx.geometry_changed()
+            fr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+            fctx.synchronize()
+            torch.cuda.synchronize()
+            verified = bool(torch.equal(fr.image, last.image))
+            log("[bench] verify: gathered image %s the single-context frame" % ("==" if verified else "!="))
+            del fr, fctx
     tot = torch.tensor([elapsed, float(rays_rank)], dtype=torch.float64, device="cpu" if rehearse else ctx.device)
     if dist is not None:
         mx = tot.clone()
@@ -498,6 +527,7 @@ def main():
         "frame_hbm": frame_hbm,
         "work_reduction": work_reduction,
         "cpu_baseline": cpu,
+        "verified_against_single_context_frame": verified,
         "repeat_ms_per_step": [round(x, 4) for x in repeats],
         "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),

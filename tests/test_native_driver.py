@@ -77,3 +77,25 @@ def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect
                    uniform_dims=(128, 128, 64), frame_cnt=2)
     np.testing.assert_array_equal(got, want["image"])
     assert want["image"].max() > 0 and want["is_shadowed"].sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--shard-builds"], ["--config3"]])
+def test_bench_two_ranks_on_one_gpu_gather_the_right_image(extra):
+    """The N > 1 path of bench.py end to end with the real kernels: two ranks (both on this one GPU, gloo with host
+    staging: a rehearsal, not RCCL) render their bands with two frames in flight and builds that never wait, rank 0
+    gathers them, and the gathered image equals the same frame rendered whole by one context."""
+    import json
+    import sys
+
+    env = dict(os.environ, UGRT_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + (os.getpid() % 300)
+    scale = ["--scale", "0.05"] if "--config3" not in extra else ["--scale", "0.02"]
+    size = [] if "--config3" in extra else ["--width", "640", "--height", "360"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "2", "--cpu-seconds", "0", "--repeats", "0", "--verify"] + scale + size + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["verified_against_single_context_frame"] is True

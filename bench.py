@@ -392,6 +392,25 @@ def main():
     prof_full = merged_prof()
     for c in profiled:
         c.prof_enable(False)
+    # the same stage table with every kernel alone on the chip: one context, one stream, one frame at a time
+    # (what a stage costs, as opposed to how long it lasts beside the kernels of three other streams)
+    alone = None
+    if rank == 0 and not args.animate and shards is None:
+        actx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
+        ar = ugrt.Renderer(actx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+        for kv in opts:
+            k, v = kv.split("=")
+            if k != "dda_blocks":
+                actx.set_option(k, int(v))
+        for i in range(3 + nfull):
+            if i == 3:
+                actx.synchronize()
+                actx.prof_enable(True)
+                actx.prof_reset()
+            ar.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+        actx.synchronize()
+        alone = {k: round(v[0] / nfull, 4) for k, v in sorted(actx.prof_get().items()) if v[1]}
+        del ar, actx
 
     verified = None
     if args.verify:
@@ -532,6 +551,7 @@ def main():
         "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
+        "stages_ms_per_step_alone_on_one_stream": alone,
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},
     }
     if args.stages_json:

@@ -714,7 +714,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	G.r_exact = false;
 	G.active_cells = active;
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REPORT + 2 * gi, report, 8, hipMemcpyDeviceToHost, st));
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + gi, used, 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_CELLS_USED + gi, used, 4, hipMemcpyDeviceToHost, st));
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_STATUS, status, 4, hipMemcpyDeviceToHost, st));
 	G.async_pending = true;
 	G.valid = true;
@@ -750,9 +750,9 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		return rc;
 	// total_triangles, frustum_grid.h:254 (the one unavoidable read-back: it sizes the lists), here
 	// as narrow references + number of wide triangles
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned, (u32 *)G.scan.p + (F - 1), 8, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_RW, (u32 *)G.scan.p + (F - 1), 8, hipMemcpyDeviceToHost, st));
 	UGRT_HIP(hipStreamSynchronize(st));
-	const u32 Rn = ctx->h_pinned[0], W = ctx->h_pinned[1];
+	const u32 Rn = ctx->h_pinned[UGRT_PIN_RW], W = ctx->h_pinned[UGRT_PIN_RW + 1];
 	WideBox wb;
 	wb.W = W;
 	wb.ny = (u32)ny;
@@ -852,7 +852,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	}
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
 	// "Number of actual cells" (frustum_grid.h:337): fetched lazily by ugrt_grid_get_info
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + (&G - ctx->grid), used, 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_CELLS_USED + (&G - ctx->grid), used, 4, hipMemcpyDeviceToHost, st));
 	G.valid = true;
 	return UGRT_OK;
 }
@@ -1112,7 +1112,7 @@ extern "C" int ugrt_grid_merge_shards(ugrt_ctx *ctx, int which, int nparts, cons
 		UGRT_HIP(hipGetLastError());
 	}
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 4 + which, used, 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_CELLS_USED + which, used, 4, hipMemcpyDeviceToHost, st));
 	G.keys = (u32 *)G.key[0].p;
 	G.vals = (u32 *)G.val[0].p;
 	G.R = (u32)Rtot;

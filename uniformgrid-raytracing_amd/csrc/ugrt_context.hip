@@ -87,9 +87,9 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 	ctx->cam.H = cfg->height;
 	ctx->cam.nbx = nbx;
 	ctx->cam.nby = nby;
-	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, 64 * sizeof(u32), hipHostMallocDefault);
+	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, UGRT_PIN_WORDS * sizeof(u32), hipHostMallocDefault);
 	if (e == hipSuccess)
-		memset(ctx->h_pinned, 0, 64 * sizeof(u32));
+		memset(ctx->h_pinned, 0, UGRT_PIN_WORDS * sizeof(u32));
 	if (e == hipSuccess)
 		e = hipMalloc((void **)&ctx->d_small, UGRT_DSMALL_WORDS * sizeof(u32));
 	if (e == hipSuccess)
@@ -191,7 +191,8 @@ static const struct {
 	{ "primary_seg", 64, 1 << 20 }, { "shadow_beam", 64, 8192 },
 	{ "shadow_xseg", 64, 1 << 20 }, { "shadow_sizebits", 0, 8 },    { "shadow_itemsort", 0, 1 },
 	{ "shadow_mbits", 1, 24 },      { "shadow_key64", 0, 1 },       { "sort_library", 0, 1 },
-	{ "async_build", 0, 1 },
+	{ "async_build", 0, 1 },        { "primary_waves", 64, 1 << 20 },
+	{ "shadow_waves", 64, 1 << 20 },
 };
 
 extern "C" int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value)
@@ -312,7 +313,7 @@ extern "C" int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out)
 		out->total_refs = (unsigned)(ctx->h_pinned[UGRT_PIN_REPORT + 2 * which] +
 					     G.active_cells * ctx->h_pinned[UGRT_PIN_REPORT + 2 * which + 1]);
 	out->num_cells = G.C;
-	out->cells_used = ctx->h_pinned[4 + which];
+	out->cells_used = ctx->h_pinned[UGRT_PIN_CELLS_USED + which];
 	return UGRT_OK;
 }
 
@@ -426,8 +427,8 @@ extern "C" int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8])
 	if (ctx->shadow_async_pending)
 		stats[1] = ctx->h_pinned[UGRT_PIN_SHADOW + 1];
 	if (ctx->stats[2]) { // the shadow tracer ran: its work counters were copied to pinned memory
-		memcpy(&stats[6], ctx->h_pinned + 14, 8);
-		memcpy(&stats[7], ctx->h_pinned + 16, 8);
+		memcpy(&stats[6], ctx->h_pinned + UGRT_PIN_SHADOW_WORK, 8);
+		memcpy(&stats[7], ctx->h_pinned + UGRT_PIN_SHADOW_WORK + 2, 8);
 	}
 	return UGRT_OK;
 }

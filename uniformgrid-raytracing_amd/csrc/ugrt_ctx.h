@@ -34,6 +34,8 @@ enum {
 	UGRT_OPT_SHADOW_KEY64,     // "shadow_key64"
 	UGRT_OPT_SORT_LIBRARY,     // "sort_library": 1 = rocPRIM radix sort instead of the built-in one
 	UGRT_OPT_ASYNC_BUILD,      // "async_build": 1 = grid builds and the shadow tracer never wait for the device
+	UGRT_OPT_PRIMARY_WAVES,    // "primary_waves": single-wave workgroups of the primary tracer
+	UGRT_OPT_SHADOW_WAVES,     // "shadow_waves": the same for the two shadow kernels
 	UGRT_OPT_COUNT
 };
 
@@ -62,23 +64,39 @@ struct Grid {
 	bool valid = false;
 };
 
-// layout of ugrt_ctx::d_small (u32 words): [0,32) totals and tracer counters, [32,132) the 5x5x4 direction
-// table, [132, 236) the DDA's work counters (u64), [236, 264) counts of asynchronous builds / shadow passes
-#define UGRT_DSMALL_TICKET 8
-#define UGRT_DSMALL_STATUS 14 // status bits of asynchronous calls
-#define UGRT_DSMALL_RW 236     // [3][2] checked {narrow references, wide triangles} of an asynchronous build
-#define UGRT_DSMALL_REPORT 242 // [3][2] the same as found (what the next build is sized by)
-#define UGRT_DSMALL_SHADOW 248 // [8] asynchronous shadow tracer: checked and reported counts
-#define UGRT_PIN_STATUS 20
-#define UGRT_PIN_REPORT 22
-#define UGRT_PIN_SHADOW 30 // {pairs, beams} of the last asynchronous shadow pass
+// layout of ugrt_ctx::d_small (u32 words of device scratch)
+#define UGRT_DSMALL_DDA_RAYS 2     // secondary rays in the DDA's ray list
+#define UGRT_DSMALL_WIDE 3         // wide triangles of the running build
+#define UGRT_DSMALL_TICKET 8       // group ticket of the beam DDA
+#define UGRT_DSMALL_STATUS 14      // status bits of asynchronous calls
+#define UGRT_DSMALL_SHADOW_WORK 16 // u64 [2]: cull tests, staged candidates of the shadow pass (FLAG_COUNT_WORK)
+#define UGRT_DSMALL_PAIRS 20       // candidate pairs of the shadow pass (cleared with the two counters before it)
+#define UGRT_DSMALL_TEX 32         // [100] the 5x5x4 direction table
+#define UGRT_DSMALL_DDA 132        // u64 [UGRT_DDA_STATS] work counters of the DDA
+#define UGRT_DSMALL_RW 236         // [3][2] checked {narrow references, wide triangles} of an asynchronous build
+#define UGRT_DSMALL_REPORT 242     // [3][2] the same as found (what the next build is sized by)
+#define UGRT_DSMALL_SHADOW 248     // [8] asynchronous shadow tracer: checked and reported counts
+#define UGRT_DSMALL_PRIMARY 264    // u64 [UGRT_PRIMARY_STATS] work counters of the primary tracer (FLAG_COUNT_WORK)
+#define UGRT_DSMALL_WORDS (132 + 104 + 28 + 32)
+// layout of ugrt_ctx::h_pinned (u32 words of pinned host memory for small read-backs)
+#define UGRT_PIN_RW 0           // {narrow references, wide triangles} of the running (waiting) build
+#define UGRT_PIN_CELLS_USED 4   // [3] per grid
+#define UGRT_PIN_REFS 8         // ugrt_refs_of: last span, last offset
+#define UGRT_PIN_PAIRS 10       // candidate pairs of the shadow pass
+#define UGRT_PIN_CHUNKS 11      // chunks of ugrt_sort_rays
+#define UGRT_PIN_BEAMS 12       // beams of the shadow pass
+#define UGRT_PIN_SHADOW_WORK 14 // u64 [2]: copy of UGRT_DSMALL_SHADOW_WORK
+#define UGRT_PIN_STATUS 20      // copy of UGRT_DSMALL_STATUS
+#define UGRT_PIN_REPORT 22      // [3][2] copy of UGRT_DSMALL_REPORT
+#define UGRT_PIN_SHADOW 30      // {pairs, beams} of the last asynchronous shadow pass
+#define UGRT_PIN_WORDS 64
 #define UGRT_STATUS_BUILD_OVERFLOW 1u
 #define UGRT_STATUS_PAIR_OVERFLOW 2u
 #define UGRT_STATUS_ITEM_OVERFLOW 4u
-#define UGRT_DSMALL_TEX 32
-#define UGRT_DSMALL_DDA 132
-#define UGRT_DSMALL_WORDS (132 + 104 + 28)
 #define UGRT_DDA_STATS 46
+#define UGRT_PRIMARY_STATS 16
+static_assert(UGRT_DSMALL_DDA + 2 * UGRT_DDA_STATS <= UGRT_DSMALL_RW, "the DDA's counters run into the build counts");
+static_assert(UGRT_DSMALL_SHADOW + 8 <= UGRT_DSMALL_PRIMARY && UGRT_DSMALL_PRIMARY + 2 * UGRT_PRIMARY_STATS <= UGRT_DSMALL_WORDS && UGRT_PIN_SHADOW + 2 <= UGRT_PIN_WORDS, "scratch layout");
 
 struct ProfPair {
 	hipEvent_t a, b;
@@ -113,10 +131,8 @@ struct ugrt_ctx {
 	DevBuf sray;                                         // shadow tracer: rebuilt rays {direction, distance}, beam order
 	DevBuf citem;                                        // shadow tracer: light cell of every cull item
 	DevBuf sitem;                                        // shadow tracer: exact-pass item list (segment, beam|sub) x2
-	// 32 u32 of pinned host memory for small read-backs: [0,1] narrow refs + wide triangles of the running build,
-	// [4..6] cells_used per grid, [8,9] refs_of, [10] candidate pairs, [11] chunks, [12] beams, [14..17] shadow work counters
-	u32 *h_pinned = nullptr;
-	u32 *d_small = nullptr;       // device scratch words (totals, counters, the direction table)
+	u32 *h_pinned = nullptr; // pinned host words for small read-backs (UGRT_PIN_*)
+	u32 *d_small = nullptr;  // device scratch words (UGRT_DSMALL_*)
 	unsigned prof_mask = 0; // bit s = stage s is timed
 	unsigned chunk_capacity = 0; // prefix_capacity of the last ugrt_sort_rays
 	const unsigned *chunk_prefix = nullptr, *chunk_map = nullptr; // and the arrays it sorted / wrote
@@ -129,6 +145,7 @@ struct ugrt_ctx {
 	bool have_shadow_est = false, shadow_async_pending = false;
 	unsigned long long stats[8] = { 0 };
 	unsigned long long dda_stats[UGRT_DDA_STATS] = { 0 }; // ugrt_stats_dda
+	unsigned long long primary_stats[UGRT_PRIMARY_STATS] = { 0 }; // ugrt_stats_primary
 };
 
 #define UGRT_HIP(call)                                                                            \
@@ -144,7 +161,7 @@ int ugrt_buf_reserve(ugrt_ctx *ctx, DevBuf &b, size_t bytes);
 int ugrt_slab_union(ugrt_ctx *ctx, const u32 *d_span, const u32 *d_offset, u32 C, u32 slabs, const u32 **uspan,
 		    const u32 **uoffset);
 float *ugrt_ctx_tex(ugrt_ctx *ctx); // device copy of the 5x5x4 direction table
-static inline u32 *ugrt_wide_counter(ugrt_ctx *ctx) { return ctx->d_small + 3; } // wide triangles of the running build
+static inline u32 *ugrt_wide_counter(ugrt_ctx *ctx) { return ctx->d_small + UGRT_DSMALL_WIDE; }
 void ugrt_prof_begin(ugrt_ctx *ctx, int stage);
 void ugrt_prof_end(ugrt_ctx *ctx, int stage);
 

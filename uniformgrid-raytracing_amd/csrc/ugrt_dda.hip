@@ -836,7 +836,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	int rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)ctx->npix * 4)))
 		return rc;
-	u32 *list = (u32 *)ctx->wscan.p, *dcount = ctx->d_small + 2;
+	u32 *list = (u32 *)ctx->wscan.p, *dcount = ctx->d_small + UGRT_DSMALL_DDA_RAYS;
 	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
 	const float4 *rec = use_rec ? (const float4 *)ctx->trirec.p : (const float4 *)nullptr;
 	const bool counting = (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) != 0;

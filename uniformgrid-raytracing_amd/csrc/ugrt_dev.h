@@ -174,6 +174,23 @@ __device__ __forceinline__ bool d_mt_core(const float *tvec, const float *edge1,
 	return true;
 }
 
+// how far d_mt_core gets (work counters only): 0 = |det| < eps, 1 = u outside, 2 = v or u+v outside, 3 = t computed
+__device__ __forceinline__ int d_mt_stage(const float *tvec, const float *edge1, const float *edge2, const float *dir)
+{
+	float pvec[3], qvec[3];
+	D_CROSS(pvec, dir, edge2);
+	float det = D_DOT(edge1, pvec);
+	if (det > -D_EPSILON && det < D_EPSILON)
+		return 0;
+	float inv_det = 1.0f / det;
+	float u = D_DOT(tvec, pvec) * inv_det;
+	if (u < 0.0f || u > 1.0f)
+		return 1;
+	D_CROSS(qvec, tvec, edge1);
+	float v = D_DOT(dir, qvec) * inv_det;
+	return (v < 0.0f || u + v > 1.0f) ? 2 : 3;
+}
+
 // trace_kernel.cu:4-45 intersectTriUV: |t|, accepted when 0 < t < oldt
 __device__ __forceinline__ float d_intersect_tri_uv(const float *tvec, const float *edge1, const float *edge2,
 						    const float *dir, float oldt)

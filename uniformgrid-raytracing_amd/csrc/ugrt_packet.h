@@ -155,7 +155,7 @@ __device__ __forceinline__ u32 d_rank_in_mask(unsigned long long mask)
 // centre +- half width: f(d) = n.d ranges over n.c -+ sum_k |n_k| r_k.
 struct CullTri {
 	float nA[3], nB[3], nC[3], nD[3];
-	float mA, mB, mD;
+	float mA, mB, mD, mT;
 };
 struct CBox {
 	float c[3], r[3];
@@ -180,7 +180,26 @@ __device__ __forceinline__ CullTri d_cull_prep(const float *tv, const float *e1,
 	t.mA = fmaxf(K * a * c, 1e-25f);
 	t.mB = fmaxf(K * a * b, 1e-25f);
 	t.mD = fmaxf(K * b * c, 1e-25f);
+	t.mT = K * a * b * c;
 	return t;
+}
+
+// Lower bound of the |t| that intersectTriUV computes for ANY direction of the box (0 = no bound).
+// t = T * (1 / det) with T = e2.(tvec x e1), the same for every ray, and det = d.(e2 x e1).  The exact path
+// rounds T within ~2^-21 a b c of its true value (mT is 2^6 times that) and its det stays inside the interval
+// the cull tests the sign of (|Dm| + Dr + mD, margins as there), so
+//   |t| >= (|T| - mT) / (|Dm| + Dr + mD) * (1 - 2^-22),
+// and the factor below leaves 2^-13 for the reciprocal's ulp and the two roundings.  A triangle whose bound
+// exceeds the closest hit of every ray of a packet cannot be accepted by any of them (strict t < oldt).
+__device__ __forceinline__ float d_cull_tlow(const CullTri &t, const float *e2, const CBox &bx)
+{
+#pragma clang fp contract(fast)
+	const float Dm = t.nD[0] * bx.c[0] + t.nD[1] * bx.c[1] + t.nD[2] * bx.c[2];
+	const float Dr = fabsf(t.nD[0]) * bx.r[0] + fabsf(t.nD[1]) * bx.r[1] + fabsf(t.nD[2]) * bx.r[2];
+	const float T = fabsf(e2[0] * t.nB[0] + e2[1] * t.nB[1] + e2[2] * t.nB[2]) - t.mT;
+	const float bound = fabsf(Dm) + Dr + t.mD;
+	const float lo = T * __builtin_amdgcn_rcpf(bound) * 0.9998779296875f;
+	return lo > 0.0f ? lo : 0.0f; // (a NaN ends here as 0 too)
 }
 
 __device__ __forceinline__ bool d_cull_cr(const CullTri &t, const CBox &bx)
@@ -211,10 +230,9 @@ __device__ __forceinline__ float d_readlane(float v, int l)
 
 
 // persistent launches: 256 CUs x 8 single-wave workgroups per SIMD-quad
-static inline int launch_blocks_for(u32 upper)
+static inline int launch_blocks_for(u32 upper, int waves = -1)
 {
-	// 256 CUs x 8 single-wave workgroups per SIMD-quad; waves are persistent
-	u32 g = 256u * 32u;
+	u32 g = waves > 0 ? (u32)waves : 256u * 32u;
 	if (upper < g)
 		g = upper ? upper : 1u;
 	return (int)g;

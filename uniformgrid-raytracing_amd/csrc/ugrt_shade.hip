@@ -170,7 +170,7 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 	}
 	UGRT_HIP(hipGetLastError());
 	// h_numCudaBlocks, decision_data.h:264
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 11, (u32 *)ctx->cbase.p + (ncell - 1), 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_CHUNKS, (u32 *)ctx->cbase.p + (ncell - 1), 4, hipMemcpyDeviceToHost, st));
 	ugrt_prof_end(ctx, UGRT_ST_SORT_RAYS);
 	ctx->chunk_capacity = prefix_capacity;
 	ctx->chunk_prefix = d_prefix_map;
@@ -186,7 +186,7 @@ extern "C" int ugrt_sort_rays_chunks(ugrt_ctx *ctx, unsigned *num_chunks)
 		return ugrt_fail(UGRT_EINVAL, "sort_rays_chunks: null argument");
 	UGRT_HIP(hipSetDevice(ctx->device));
 	UGRT_HIP(hipStreamSynchronize(ctx->stream));
-	*num_chunks = ctx->h_pinned[11];
+	*num_chunks = ctx->h_pinned[UGRT_PIN_CHUNKS];
 	if (*num_chunks > ctx->chunk_capacity)
 		return ugrt_fail(UGRT_EINVAL, "sort_rays: %u chunks do not fit prefix_capacity %u", *num_chunks,
 				 ctx->chunk_capacity);

@@ -125,35 +125,91 @@ __device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const Primar
 }
 
 #define SURV_CAP 128 // survivors buffered in LDS before the per-lane tests run (flush at >= 64)
+#define JOB_CAP (4 * SURV_CAP)
+#ifndef JOB_CHUNK
+#define JOB_CHUNK 64u // jobs between two looks at the rays' closest hits
+#endif
 
 // One wave per item = (8x8-pixel tile, segment of its cell list).  lane = triangle: cull against the
 // tile's direction box, then against the boxes of its four 4x4-pixel QUADRANTS; survivors go to LDS once
-// and their slot numbers into one list per quadrant.  lane = pixel: every lane walks the list of ITS
-// quadrant, so the 64 lanes test up to four different triangles at a time and a small triangle costs a
-// quarter of the lanes instead of the whole wave.  Lists keep the cell-list order, which the reference's
-// strict "<" needs (first of equal t wins).
-template <bool REC>
-__global__ __launch_bounds__(64, 5) void k_trace_primary(CamBlock cam, const float *__restrict__ tex,
+// and every (survivor, quadrant it may touch) pair becomes a JOB.  lane = (job of the round, ray of that
+// job's quadrant): a round runs four jobs of ANY quadrants, so a small triangle costs a quarter of the lanes
+// and a tile whose triangles crowd into one quadrant still fills the wave (with one list per quadrant the
+// rounds of a flush were those of its longest list: 1.53 M rounds for 2.57 M jobs on the bench frame).
+// A ray is then tested by different lanes in different rounds, so its closest hit is merged in LDS as
+// min over (t bits << 32 | position in the cell list): the smallest t, and of equal t's the first of the
+// list -- what the reference's strict "<" in list order keeps.
+// qfar[q] = the largest of the closest-hit distances of quadrant q's 16 rays (lane bits 2 and 5 select the
+// quadrant), NaN (bits ~0) while one of them has no hit: positive floats and that sentinel order as unsigned ints
+__device__ __forceinline__ void d_quadrant_far(const unsigned long long *s_best, int lane, float *qfar)
+{
+	u32 tb = (u32)(s_best[lane] >> 32);
+#pragma unroll
+	for (int m = 1; m <= 16; m <<= 1) {
+		if (m == 4)
+			continue;
+		const u32 o = (u32)__shfl_xor((int)tb, m);
+		tb = o > tb ? o : tb;
+	}
+#pragma unroll
+	for (int q = 0; q < 4; q++)
+		qfar[q] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)tb, ((q & 1) << 2) | ((q & 2) << 4)));
+}
+
+// work counters of the COUNT variant (ugrt_stats_primary)
+enum { PS_ITEMS, PS_BATCHES, PS_BATCHES_KEPT, PS_REFS, PS_TILE_SURVIVORS, PS_SURVIVORS, PS_JOBS, PS_FLUSHES, PS_ROUNDS,
+       PS_ROUNDS_DIV, PS_ROUNDS_V, PS_ROUNDS_T, PS_LANE_TESTS, PS_HITS, PS_END };
+static_assert(PS_END <= UGRT_PRIMARY_STATS, "primary work counters");
+
+template <bool REC, bool COUNT>
+__global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const float *__restrict__ tex,
 						       const WItem *__restrict__ items,
 						       const u32 *__restrict__ nitems_p,
 						       const u32 *__restrict__ value_list,
 						       const float *__restrict__ verts, const int *__restrict__ tris,
 						       const float4 *__restrict__ rec, PrimaryOut out,
-						       u64 *__restrict__ best, int p0)
+						       u64 *__restrict__ best, int p0, unsigned long long *__restrict__ counters)
 {
 	__shared__ __attribute__((aligned(16))) float lds[SURV_CAP * TRI_STRIDE];
-	__shared__ unsigned short qlist[4][SURV_CAP];
+	__shared__ unsigned short jobs[JOB_CAP]; // survivor slot | lane offset of the quadrant << 7
+	__shared__ unsigned short ready[64];     // the jobs of the current 64 that are still worth their tests
+	__shared__ float s_dir[64 * 3];
+	__shared__ unsigned long long s_best[64];
 	const int lane = threadIdx.x;
-	const int myq = ((lane >> 2) & 1) | ((lane >> 4) & 2); // quadrant of this lane's pixel (col bit 2, row bit 2)
+	// a job's 16 rays: lane bits 0,1 (column) and 3,4 (row) inside the quadrant; the quadrant adds bits 2 and 5
+	const int group = lane >> 4, rbase = (lane & 3) | (((lane >> 2) & 3) << 3);
 	const u32 nitems = *nitems_p;
 	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
+	unsigned long long ps[PS_END] = { 0 };
 	for (u32 it = d_xcd_block(); it < nitems; it += gridDim.x) {
 		const WItem w = items[it];
+		if (COUNT) {
+			ps[PS_ITEMS]++;
+			ps[PS_REFS] += w.count;
+		}
+		// Two dependent gathers stand before every batch of 64 references (id, then record); issued where
+		// they are needed, a wave spends three quarters of a batch waiting for them.  So they run one batch
+		// ahead: the records of the next batch and the ids of the one after are in flight while the current
+		// one is culled, and the item's first batch while its rays are set up.  (Indices are clamped to the
+		// item's last reference instead of being masked: loads under a divergent branch make the compiler
+		// wait for everything outstanding at the join.)
+		const u32 last = w.count ? w.count - 1u : 0u;
+		u32 id_next = 0;
+		float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+		float rcx = 0.f;
+		if (REC && w.count)
+			id_next = value_list[w.begin + min((u32)lane, last)];
 		const int bx = (int)(w.cell / (u32)cam.nby), by = (int)(w.cell % (u32)cam.nby);
 		const int col = bx * 8 + (lane & 7), row = by * 8 + (lane >> 3);
 		const int pixelID = row * cam.W + col;
 		float dir[3];
 		d_ray_dir(cam, tex, col, row, dir);
+		if (REC && w.count) {
+			ra = rec[id_next * 3u + 0u];
+			rb = rec[id_next * 3u + 1u];
+			rcx = reinterpret_cast<const float *>(rec)[id_next * 12u + 8u];
+			id_next = value_list[w.begin + min(64u + (u32)lane, last)];
+		}
 		// direction boxes: reduce inside the quadrants (lane bits 0,1,3,4), then across them (bits 2,5);
 		// centre and half width are formed per lane and read from one lane of each quadrant, so that
 		// the boxes live in scalar registers
@@ -183,27 +239,51 @@ __global__ __launch_bounds__(64, 5) void k_trace_primary(CamBlock cam, const flo
 				qb[q].r[k] = d_readlane(qr, src);
 			}
 		}
-		float oldt = 99999999.9f;
-		u32 ref = 0xFFFFFFFFu;
-		u32 nsurv = 0, qn[4] = { 0, 0, 0, 0 };
+		s_dir[lane * 3 + 0] = dir[0];
+		s_dir[lane * 3 + 1] = dir[1];
+		s_dir[lane * 3 + 2] = dir[2];
+		s_best[lane] = ~0ull;
+		u32 nsurv = 0, njobs = 0;
+		// per quadrant: the farthest of its 16 rays' closest hits so far (NaN while a ray has none)
+		float qfar[4] = { __uint_as_float(~0u), __uint_as_float(~0u), __uint_as_float(~0u), __uint_as_float(~0u) };
 		for (u32 b = 0; b < w.count || nsurv; b += 64) {
 			if (b < w.count) {
 				const u32 cnt = (w.count - b) < 64u ? (w.count - b) : 64u;
 				bool keep = false;
 				float t9[9];
 				CullTri ct;
-				if ((u32)lane < cnt) {
+				if (REC) {
+					// (the same subtractions d_load_triangle makes)
+					t9[0] = ex - ra.x, t9[1] = ey - ra.y, t9[2] = ez - ra.z;
+					t9[3] = ra.w, t9[4] = rb.x, t9[5] = rb.y, t9[6] = rb.z, t9[7] = rb.w, t9[8] = rcx;
+					ra = rec[id_next * 3u + 0u];
+					rb = rec[id_next * 3u + 1u];
+					rcx = reinterpret_cast<const float *>(rec)[id_next * 12u + 8u];
+					id_next = value_list[w.begin + min(b + 128u + (u32)lane, last)];
+					if ((u32)lane < cnt) {
+						ct = d_cull_prep(&t9[0], &t9[3], &t9[6]);
+						keep = !d_cull_cr(ct, tb);
+					}
+				} else if ((u32)lane < cnt) {
 					d_load_triangle<REC>(rec, verts, tris, value_list[w.begin + b + lane], ex, ey, ez, t9);
 					ct = d_cull_prep(&t9[0], &t9[3], &t9[6]);
 					keep = !d_cull_cr(ct, tb);
 				}
+				if (COUNT) {
+					ps[PS_BATCHES]++;
+					ps[PS_TILE_SURVIVORS] += (u32)__popcll(__ballot(keep));
+				}
 				if (__ballot(keep) != 0ull) {
 					u32 km = 0;
+					float tlow = 0.0f;
 					if (keep) {
+						tlow = d_cull_tlow(ct, &t9[6], tb);
 #pragma unroll
 						for (int q = 0; q < 4; q++)
-							km |= d_cull_cr(ct, qb[q]) ? 0u : (1u << q);
+							km |= (d_cull_cr(ct, qb[q]) || tlow > qfar[q]) ? 0u : (1u << q);
 					}
+					if (COUNT)
+						ps[PS_BATCHES_KEPT]++;
 					keep = km != 0u;
 					const unsigned long long mask = __ballot(keep);
 					const u32 slot = nsurv + d_rank_in_mask(mask);
@@ -211,54 +291,94 @@ __global__ __launch_bounds__(64, 5) void k_trace_primary(CamBlock cam, const flo
 						float4 *dst = reinterpret_cast<float4 *>(&lds[slot * TRI_STRIDE]);
 						dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
 						dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
-						dst[2] = make_float4(t9[8], __uint_as_float(w.begin + b + lane), 0.0f, 0.0f);
+						dst[2] = make_float4(t9[8], __uint_as_float(w.begin + b + lane), tlow, 0.0f);
 					}
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
 						const unsigned long long mq = __ballot((km >> q) & 1u);
+						const u32 qoff = (u32)(((q & 1) << 2) | ((q & 2) << 4));
 						if ((km >> q) & 1u)
-							qlist[q][qn[q] + d_rank_in_mask(mq)] = (unsigned short)slot;
-						qn[q] += (u32)__popcll(mq);
+							jobs[njobs + d_rank_in_mask(mq)] = (unsigned short)(slot | (qoff << 7));
+						njobs += (u32)__popcll(mq);
 					}
 					nsurv += (u32)__popcll(mask);
 				}
 				if (nsurv < 64u && b + 64 < w.count)
 					continue; // keep collecting
 			}
-			// lane = pixel: the exact per-ray test of the reference on the survivors of its quadrant
+			// The jobs are taken 64 at a time.  lane = job: a job whose triangle lies behind the closest hits of all
+			// 16 rays of its quadrant is dropped (the rays of the bench scene cross eleven surfaces each; lists are
+			// in id order, so most triangles come after a nearer one).  lane = (job, ray): the exact per-ray test
+			// of the reference, four of the remaining jobs a round.
 			__syncthreads();
-			const u32 mine = myq == 0 ? qn[0] : (myq == 1 ? qn[1] : (myq == 2 ? qn[2] : qn[3]));
-			const u32 longest = max(max(qn[0], qn[1]), max(qn[2], qn[3]));
-			for (u32 k = 0; k < longest; k++) {
-				if (k < mine) {
-					const float4 *src = reinterpret_cast<const float4 *>(&lds[(u32)qlist[myq][k] * TRI_STRIDE]);
-					const float4 a = src[0], c = src[1], e = src[2];
-					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
-					const float v = d_intersect_tri_uv(tv, e1, e2, dir, oldt);
-					if (v != 0.0f) {
-						oldt = v;
-						ref = __float_as_uint(e.y);
+			if (COUNT) {
+				ps[PS_FLUSHES]++;
+				ps[PS_SURVIVORS] += nsurv;
+				ps[PS_JOBS] += njobs;
+			}
+			for (u32 j0 = 0; j0 < njobs; j0 += JOB_CHUNK) {
+				d_quadrant_far(s_best, lane, qfar);
+				bool live = false;
+				u32 myjob = 0;
+				if ((u32)lane < JOB_CHUNK && j0 + (u32)lane < njobs) {
+					myjob = jobs[j0 + (u32)lane];
+					const float tlow = lds[(myjob & 127u) * TRI_STRIDE + 10u];
+					const u32 qo = myjob >> 7;
+					const float far = qo == 0u ? qfar[0] : (qo == 4u ? qfar[1] : (qo == 32u ? qfar[2] : qfar[3]));
+					live = !(tlow > far);
+				}
+				const unsigned long long lm = __ballot(live);
+				const u32 nready = (u32)__popcll(lm);
+				if (live)
+					ready[d_rank_in_mask(lm)] = (unsigned short)myjob;
+				__syncthreads();
+				for (u32 r0 = 0; r0 < nready; r0 += 4u) {
+					int stage = -1;
+					if (r0 + (u32)group < nready) {
+						const u32 job = ready[r0 + (u32)group];
+						const int home = rbase | (int)(job >> 7);
+						const float4 *src = reinterpret_cast<const float4 *>(&lds[(job & 127u) * TRI_STRIDE]);
+						const float4 a = src[0], c = src[1], e = src[2];
+						const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
+						const float rd[3] = { s_dir[home * 3 + 0], s_dir[home * 3 + 1], s_dir[home * 3 + 2] };
+						const float v = d_intersect_tri_uv(tv, e1, e2, rd, 99999999.9f);
+						if (v != 0.0f)
+							atomicMin(&s_best[home], ((unsigned long long)__float_as_uint(v) << 32) |
+											 (unsigned long long)__float_as_uint(e.y));
+						if (COUNT)
+							stage = v != 0.0f ? 4 : d_mt_stage(tv, e1, e2, rd);
+					}
+					if (COUNT) {
+						ps[PS_ROUNDS]++;
+						ps[PS_ROUNDS_DIV] += __ballot(stage >= 1) != 0ull;
+						ps[PS_ROUNDS_V] += __ballot(stage >= 2) != 0ull;
+						ps[PS_ROUNDS_T] += __ballot(stage >= 3) != 0ull;
+						ps[PS_LANE_TESTS] += (u32)__popcll(__ballot(stage >= 0));
+						ps[PS_HITS] += (u32)__popcll(__ballot(stage == 4));
 					}
 				}
+				__syncthreads();
 			}
+			d_quadrant_far(s_best, lane, qfar); // for the culls of the batches to come
 			__syncthreads();
 			nsurv = 0;
-			qn[0] = qn[1] = qn[2] = qn[3] = 0;
+			njobs = 0;
 		}
+		const unsigned long long mine = s_best[lane];
 		if (!w.multi) {
-			d_finish_pixel<REC>(cam, out, pixelID, dir, oldt, ref, value_list, verts, tris, rec);
-		} else if (ref != 0xFFFFFFFFu) {
-			atomicMin(reinterpret_cast<unsigned long long *>(&best[pixelID - p0]),
-				  ((unsigned long long)__float_as_uint(oldt) << 32) | (unsigned long long)ref);
+			const bool hit = mine != ~0ull;
+			d_finish_pixel<REC>(cam, out, pixelID, dir, hit ? __uint_as_float((u32)(mine >> 32)) : 99999999.9f,
+					    hit ? (u32)mine : 0xFFFFFFFFu, value_list, verts, tris, rec);
+		} else if (mine != ~0ull) {
+			atomicMin(reinterpret_cast<unsigned long long *>(&best[pixelID - p0]), mine);
 		}
 	}
+	if (COUNT && lane == 0)
+		for (int i = 0; i < PS_END; i++)
+			if (ps[i])
+				atomicAdd(&counters[i], ps[i]);
 }
 
-// rckernel_alpha with NUM_SLABS > 1 (trace_kernel.cu:132-229): one wave per tile walks the tile's slabs front to
-// back.  The reference's state machine is kept as written: a hit is accepted (rayDone = 2) in the slab whose
-// index equals floor(ndc_z * slabs); accepted rays skip the tests of the next slab; isWithin then returns 0 for
-// them (:59-62), i.e. they fall back to "no hit" with their oldt kept; the tile stops once all 64 rays are
-// accepted.  Lists are culled per batch against the tile's direction box (survivors keep the list order).
 template <bool REC>
 __global__ __launch_bounds__(64) void k_trace_primary_slabs(CamBlock cam, const float *__restrict__ tex, int slabs,
 							     int gy_lo, int rows, u32 ntiles,
@@ -405,10 +525,10 @@ static int refs_of(ugrt_ctx *ctx, const u32 *d_span, const u32 *d_offset, u32 C,
 			*R = ctx->grid[g].R;
 			return UGRT_OK;
 		}
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 8, d_span + (C - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 9, d_offset + (C - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REFS, d_span + (C - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REFS + 1, d_offset + (C - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
 	UGRT_HIP(hipStreamSynchronize(ctx->stream));
-	*R = ctx->h_pinned[8] + ctx->h_pinned[9];
+	*R = ctx->h_pinned[UGRT_PIN_REFS] + ctx->h_pinned[UGRT_PIN_REFS + 1];
 	return UGRT_OK;
 }
 
@@ -425,17 +545,18 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	const int rows = ctx->cfg.row_end - ctx->cfg.row_begin;
 	const u32 ncell = (u32)ctx->nbx * (u32)rows;
 	const u32 C = (u32)ctx->nbx * (u32)ctx->nby;
+	const float *tex = ugrt_ctx_tex(ctx); // (stores the current camera's direction table first, if it is new)
 	if (ctx->cfg.slabs > 1) { // NUM_SLABS > 1: the slab walk of trace_kernel.cu:132-229, one wave per tile
 		PrimaryOut o = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
 		const bool rec_ok = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
 		ugrt_prof_begin(ctx, UGRT_ST_TRACE_PRIMARY);
 		if (rec_ok)
 			hipLaunchKernelGGL(k_trace_primary_slabs<true>, dim3(launch_blocks_for(ncell)), dim3(64), 0, st, ctx->cam,
-					   (const float *)ugrt_ctx_tex(ctx), ctx->cfg.slabs, ctx->cfg.row_begin, rows, ncell, d_span,
+					   tex, ctx->cfg.slabs, ctx->cfg.row_begin, rows, ncell, d_span,
 					   d_offset, d_value_list, d_vertlist, d_trilist, (const float4 *)ctx->trirec.p, o);
 		else
 			hipLaunchKernelGGL(k_trace_primary_slabs<false>, dim3(launch_blocks_for(ncell)), dim3(64), 0, st, ctx->cam,
-					   (const float *)ugrt_ctx_tex(ctx), ctx->cfg.slabs, ctx->cfg.row_begin, rows, ncell, d_span,
+					   tex, ctx->cfg.slabs, ctx->cfg.row_begin, rows, ncell, d_span,
 					   d_offset, d_value_list, d_vertlist, d_trilist, (const float4 *)nullptr, o);
 		ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
 		UGRT_HIP(hipGetLastError());
@@ -471,28 +592,41 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	PrimaryOut out = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
+	// twice the waves of the other persistent kernels: 19 of these waves fit a CU (LDS), so the chip holds 4864 of
+	// them and the rest start as slots free up -- the finer the shares, the better the dispatcher evens out tiles
+	// of unequal cost (alone on the chip: 0.41 ms with 8192 waves, 0.35 ms with 16384, 0.41 ms with 20480)
+	const int pwaves = launch_blocks_for((u32)cap, ctx->opt[UGRT_OPT_PRIMARY_WAVES] > 0 ? ctx->opt[UGRT_OPT_PRIMARY_WAVES] : 16384);
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_PRIMARY);
 	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
-	if (use_rec)
-		hipLaunchKernelGGL(k_trace_primary<true>, dim3(launch_blocks_for((u32)cap)), dim3(64), 0, st, ctx->cam,
-				   (const float *)ugrt_ctx_tex(ctx), (const WItem *)items,
-				   (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist,
-				   (const float4 *)ctx->trirec.p, out, (u64 *)ctx->best.p, ctx->p0);
-	else
-		hipLaunchKernelGGL(k_trace_primary<false>, dim3(launch_blocks_for((u32)cap)), dim3(64), 0, st, ctx->cam,
-				   (const float *)ugrt_ctx_tex(ctx), (const WItem *)items,
-				   (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist,
-				   (const float4 *)nullptr, out, (u64 *)ctx->best.p, ctx->p0);
+	const bool counting = (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) != 0;
+	unsigned long long *pc = (unsigned long long *)(ctx->d_small + UGRT_DSMALL_PRIMARY);
+#define LAUNCH_PRIMARY(REC_, COUNT_)                                                                                  \
+	hipLaunchKernelGGL((k_trace_primary<REC_, COUNT_>), dim3(pwaves), dim3(64), 0, st, ctx->cam, tex,              \
+			   (const WItem *)items, (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist, \
+			   (const float4 *)(REC_ ? ctx->trirec.p : nullptr), out, (u64 *)ctx->best.p, ctx->p0, pc)
+	if (counting) {
+		UGRT_HIP(hipMemsetAsync(pc, 0, UGRT_PRIMARY_STATS * 8, st));
+		if (use_rec)
+			LAUNCH_PRIMARY(true, true);
+		else
+			LAUNCH_PRIMARY(false, true);
+		UGRT_HIP(hipMemcpyAsync(ctx->primary_stats, pc, UGRT_PRIMARY_STATS * 8, hipMemcpyDeviceToHost, st));
+	} else if (use_rec) {
+		LAUNCH_PRIMARY(true, false);
+	} else {
+		LAUNCH_PRIMARY(false, false);
+	}
+#undef LAUNCH_PRIMARY
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_PRIMARY);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
 	if (use_rec)
 		hipLaunchKernelGGL(k_resolve_primary<true>, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
-				   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist,
+				   tex, d_span, d_value_list, d_vertlist, d_trilist,
 				   (const float4 *)ctx->trirec.p, out, (u64 *)ctx->best.p, ctx->p0, ctx->npix, SEG);
 	else
 		hipLaunchKernelGGL(k_resolve_primary<false>, dim3((ctx->npix + 255) / 256), dim3(256), 0, st, ctx->cam,
-				   (const float *)ugrt_ctx_tex(ctx), d_span, d_value_list, d_vertlist, d_trilist,
+				   tex, d_span, d_value_list, d_vertlist, d_trilist,
 				   (const float4 *)nullptr, out, (u64 *)ctx->best.p, ctx->p0, ctx->npix, SEG);
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
@@ -1202,7 +1336,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	u32 *gcnt = (u32 *)ctx->scnt.p, *icnt = gcnt + C, *gincl = (u32 *)ctx->sbase.p, *iincl = gincl + C;
 	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = pstart + maxg;
 	GBox *boxes = (GBox *)ctx->sdesc.p;
-	unsigned long long *wcnt = (unsigned long long *)(ctx->d_small + 16); // [0] cull tests, [1] staged candidates
+	unsigned long long *wcnt = (unsigned long long *)(ctx->d_small + UGRT_DSMALL_SHADOW_WORK); // [0] cull tests, [1] staged candidates
 	UGRT_HIP(hipMemsetAsync(wcnt, 0, 16 + 4, st)); // + the candidate-pair cursor
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	// 1. rays: (cell, direction code) order, runs per cell, beams
@@ -1271,7 +1405,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// (option "async_build", once a synchronous pass has left estimates): no read-back; the launches are sized by
 	// the previous pass's counts plus a quarter, the kernels take the real counts from the device, and counts
 	// beyond the capacities raise a status bit instead (UGRT_EOVERFLOW at the next synchronisation).
-	u32 *pcount = ctx->d_small + 20; // right behind the work counters: cleared with them
+	u32 *pcount = ctx->d_small + UGRT_DSMALL_PAIRS; // right behind the work counters: cleared with them
 	u32 *status = ctx->d_small + UGRT_DSMALL_STATUS, *pg = ctx->d_small + UGRT_DSMALL_SHADOW, *report = pg + 2;
 	if (ctx->shadow_async_pending) { // what the last asynchronous pass needed (possibly a frame old)
 		ctx->est_pairs = ctx->h_pinned[UGRT_PIN_SHADOW];
@@ -1306,12 +1440,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			UGRT_HIP(hipMemsetAsync(pcount, 0, 4, st));
 		ugrt_prof_begin(ctx, UGRT_ST_SHADOW_CULL);
 		if (use_rec)
-			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
+			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(launch_blocks_for(0xFFFFFFFFu, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
 					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits,
 					   (const u32 *)ctx->citem.p);
 		else
-			hipLaunchKernelGGL(k_shadow_cull<false>, dim3(256 * 32), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
+			hipLaunchKernelGGL(k_shadow_cull<false>, dim3(launch_blocks_for(0xFFFFFFFFu, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
 					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits,
 					   (const u32 *)ctx->citem.p);
@@ -1335,10 +1469,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			ctx->shadow_async_pending = true;
 			break;
 		}
-		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 10, pcount, 4, hipMemcpyDeviceToHost, st));
-		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 12, gincl + (C - 1), 4, hipMemcpyDeviceToHost, st));
+		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_PAIRS, pcount, 4, hipMemcpyDeviceToHost, st));
+		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_BEAMS, gincl + (C - 1), 4, hipMemcpyDeviceToHost, st));
 		UGRT_HIP(hipStreamSynchronize(st));
-		P = ctx->h_pinned[10];
+		P = ctx->h_pinned[UGRT_PIN_PAIRS];
 		if ((size_t)P <= cap)
 			break;
 		if (attempt == 2)
@@ -1349,7 +1483,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			return rc;
 	}
 	if (!async) {
-		G = ctx->h_pinned[12];
+		G = ctx->h_pinned[UGRT_PIN_BEAMS];
 		Gcap = G;
 		ctx->stats[1] = G;
 		ctx->est_pairs = P;
@@ -1395,25 +1529,37 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		iseg1 = iseg0;
 		isub1 = isub0;
 	}
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + 14, wcnt, 16, hipMemcpyDeviceToHost, st)); // read by ugrt_stats_get
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW_WORK, wcnt, 16, hipMemcpyDeviceToHost, st)); // read by ugrt_stats_get
 	if (async)
 		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_STATUS, status, 4, hipMemcpyDeviceToHost, st));
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
 	if (use_rec)
-		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
+		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
 				   (const float4 *)ctx->sray.p, xcap);
 	else
-		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap)), dim3(64), 0, st, ctx->cam,
+		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
 				   (const float4 *)ctx->sray.p, xcap);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}
+
+// work counters of the primary tracer's last counting launch (UGRT_FLAG_COUNT_WORK), in the order of the PS_* enum
+extern "C" int ugrt_stats_primary(ugrt_ctx *ctx, unsigned long long *stats, int n)
+{
+	if (!ctx || !stats || n < 0)
+		return ugrt_fail(UGRT_EINVAL, "stats_primary: bad argument");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	for (int i = 0; i < n; i++)
+		stats[i] = i < UGRT_PRIMARY_STATS ? ctx->primary_stats[i] : 0ull;
 	return UGRT_OK;
 }

@@ -247,6 +247,16 @@ class Context:
     DDA_STATS = ("wave_iterations", "cell_groups", "group_rays", "cull_batches", "cull_tests", "exact_rounds",
                  "exact_round_rays", "lone_ray_tests")
 
+    PRIMARY_STATS = ("items", "batches", "batches_with_tile_survivors", "references", "tile_survivors",
+                     "quadrant_survivors", "jobs", "flushes", "rounds", "rounds_to_division", "rounds_to_v",
+                     "rounds_to_t", "lane_tests", "hits")
+
+    def stats_primary(self):
+        """Work counters of the primary tracer's last counting launch (a FLAG_COUNT_WORK context)."""
+        a = (C.c_ulonglong * 16)()
+        check(lib.ugrt_stats_primary(self._h, a, 16))
+        return dict(zip(self.PRIMARY_STATS, list(a)))
+
     def stats_dda(self):
         """Work sharing of the beam kernel's last counting launch (a FLAG_COUNT_WORK context)."""
         a = (C.c_ulonglong * 46)()

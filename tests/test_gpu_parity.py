@@ -535,6 +535,61 @@ def test_degenerate_triangles(ugrt, O, torch):
     assert (want["mat_ids"] >= 0).sum() > 1000
 
 
+def test_depth_layers_ties_and_grazing_triangles(ugrt, O, torch):
+    """What the primary tracer's closest-hit merge and its depth bound must get right.  Camera B looks along +z
+    into the box; in front of it stand twelve screen-filling sheets at different depths, listed in shuffled id
+    order (a farther sheet is often tested before a nearer one, and whole sheets lie behind the closest hits of
+    every ray of a tile: they are the ones the bound drops); every sheet exists twice with identical vertices,
+    the copies also shuffled (equal t: the reference's strict "<" keeps the first of the cell list); triangles
+    that the rays graze (their plane passes within 1e-3 of the eye, so det is tiny and t is ill-conditioned) lie
+    before and behind the sheets; 2000 small random triangles fill the space between.  ids, t (bits), normals,
+    shadow flags, the bounce and the image are the oracle's."""
+    s0 = scene(ugrt, "cornell")
+    rng = np.random.default_rng(20260412)
+    eye = np.array([278.0, 273.0, -800.0])
+    tris = []
+
+    def sheet(z, wob):
+        a = np.array([[-400, -400, z], [1000, -400, z + wob], [-400, 1000, z - wob]], np.float64)
+        b = np.array([[1000, 1000, z], [-400, 1000, z - wob], [1000, -400, z + wob]], np.float64)
+        return [a, b]
+
+    for k in range(12):
+        z = -500.0 + 37.0 * k
+        for _ in range(2):  # the coincident copy
+            tris += sheet(z, 3.0 * (k % 3))
+    for k in range(40):  # grazing: two vertices on a ray from the eye, the third 1e-3 off it
+        d = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 1.0])
+        d /= np.linalg.norm(d)
+        t0, t1 = rng.uniform(50, 900), rng.uniform(50, 900)
+        side = np.cross(d, [0.0, 1.0, 0.0])
+        tris.append(np.array([eye + t0 * d, eye + t1 * d, eye + 0.5 * (t0 + t1) * d + 40.0 * side + 1e-3 * np.array([0, 1.0, 0])]))
+    for k in range(2000):
+        c = np.array([rng.uniform(0, 556), rng.uniform(0, 556), rng.uniform(-600, 500)])
+        tris.append(c + rng.uniform(-12, 12, (3, 3)))
+    order = rng.permutation(len(tris))
+    extra = np.concatenate([tris[i] for i in order]).astype(np.float32)
+    verts = np.asarray(s0["verts"], np.float32).reshape(-1, 3)
+    v2 = np.concatenate([verts, extra])
+    f_extra = (len(verts) + np.arange(len(extra), dtype=np.int32)).reshape(-1, 3)
+    s = dict(s0)
+    s.update(verts=v2, faces=np.concatenate([np.asarray(s0["faces"], np.int32), f_extra]),
+             matidx=np.concatenate([np.asarray(s0["matidx"], np.int32),
+                                    rng.integers(0, len(s0["mat_list"]), len(f_extra)).astype(np.int32)]))
+    setup = setup_for(ugrt, s0, "B")
+    want = _frame_equals_oracle(ugrt, O, s, setup, 192, 160, (32, 32), (16, 16, 8))
+    ids = want["mat_ids"]
+    assert (ids >= 0).sum() > 0.9 * ids.size
+    # the work counters show that the bound was exercised: jobs were dropped before their exact tests
+    cctx = ugrt.Context(192, 160, light_grid=(32, 32), flags=ugrt.FLAG_COUNT_WORK, uniform_dims=(16, 16, 8))
+    cr = ugrt.Renderer(cctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    cr.display(setup, shadows=True, reflect=False)
+    cctx.synchronize()
+    st = cctx.stats_primary()
+    assert st["rounds"] > 0 and 4 * st["rounds"] < st["jobs"], st
+    np.testing.assert_array_equal(cr.intersect_id.cpu().numpy(), ids)
+
+
 def test_deferred_chunk_count_and_options(ugrt, O, torch):
     """ugrt_sort_rays without the read-back: the count fetched later equals the synchronous one, and the shadow
     tracer fed UGRT_CHUNKS_ON_DEVICE produces the same flags, in the reference's launch-capped mode and with

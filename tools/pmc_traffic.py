@@ -49,7 +49,8 @@ def main():
     shutil.copy(os.path.join(d, "bench_under_rocprof.json"), os.path.join(prof, tag + "_bench_under_rocprof.json"))
     fetch = counters(one("fetch/*counter_collection.csv"))
     write = counters(one("write/*counter_collection.csv"))
-    frames = len(fetch["k_trace_primary<true>"]["FETCH_SIZE"]) or 1
+    timed = [k for k in fetch if k.startswith("k_trace_primary<") and not k.endswith(", true>")]
+    frames = sum(len(fetch[k]["FETCH_SIZE"]) for k in timed) or 1
     rows, per_launch, per_frame = [], {}, {}
     for k in fetch:
         if not k.startswith("k_"):
@@ -60,8 +61,9 @@ def main():
         base = k.split("<")[0]
         rows.append({"kernel": k, "dispatches": len(f), "dispatches_per_frame": round(len(f) / frames, 2),
                      "FETCH_SIZE_KB_avg": round(favg, 1), "WRITE_SIZE_KB_avg": round(wavg, 1), "hbm_bytes_corrected": b})
-        if "<true, " in k and base == "k_trace_dda_beam" or "<true, " in k and base == "k_trace_dda_ray":
-            continue  # the counting variant runs once, outside the timed frames
+        if ("<true, " in k and base in ("k_trace_dda_beam", "k_trace_dda_ray")) or \
+                (k.endswith(", true>") and base == "k_trace_primary"):
+            continue  # the counting variants (k_trace_dda_*<COUNT, REC>, k_trace_primary<REC, COUNT>) run once, outside the timed frames
         per_launch[base] = b
         per_frame[base] = per_frame.get(base, 0) + int((2.0 * sum(f) + sum(w)) * 1024.0 / frames)
     per_launch["k_trace_dda"] = per_launch.get("k_trace_dda_beam", per_launch.get("k_trace_dda_ray", 0))

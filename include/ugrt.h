@@ -189,7 +189,8 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * cell is tested by the whole wave / a shared cell is culled before the exact tests; "primary_seg" triangles
  * per primary work item; "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits",
  * "shadow_key64" shape the shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix
- * sort instead of the built-in one.
+ * sort instead of the built-in one; "dda_blocks", "primary_waves", "shadow_waves": number of persistent
+ * single-wave workgroups of the bounce, the primary tracer and the two shadow kernels.
  * "async_build" 1: the grid builds and ugrt_trace_shadow stop waiting for the device.  The reference reads
  * total_triangles back to size its lists (frustum_grid.h:254); here the second and later builds of a grid size
  * buffers and launches by what the build before needed plus a quarter, every kernel takes the real counts from

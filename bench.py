@@ -203,6 +203,8 @@ def main():
                          "gathered image of the last step (byte for byte)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="launch-shape option for every context (ugrt_ctx_set_option), e.g. dda_kernel=1")
+    ap.add_argument("--uniform-grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
+                    help="cells of the bounce's uniform grid (A13 is this repo's own spec: any resolution gives the same hits)")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
@@ -248,6 +250,8 @@ def main():
     nby = H // 8
     rows = parallel.band_rows(rank, world, nby)
     lg, udims = (128, 128), (128, 128, 64)
+    if args.uniform_grid:
+        udims = tuple(args.uniform_grid)
 
     s = load_scene(ugrt, args.workload, args.scale, rank)
     setup = ugrt.FrameSetup.from_scene(s)

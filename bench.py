@@ -300,10 +300,22 @@ def main():
             rr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
             gather.gather(rr.image)
 
-    for _ in range(max(1, args.warmup)):
+    # the tracers' event pairs are bracketed from the first warm-up step on; after the W warm-up steps every context
+    # is run until its pool holds the pairs K timed steps take (hipEventCreate inside the timed region cost ~4 %)
+    tracers = ("trace_primary", "shadow_cull", "trace_shadow", "trace_dda")
+    profiled = [c for rr in renderers for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else [])]
+    for c in profiled:
+        c.prof_enable(True, stages=tracers)
+    warm = max(1, args.warmup)
+    for _ in range(warm):
         step()
+    if not os.environ.get("UGRT_BENCH_COLD_EVENTS"):
+        for _ in range(max(0, args.steps - warm)):
+            step()
+            warm += 1
     gather.finish()
-    ctx.synchronize()
+    for rr in renderers:
+        rr.synchronize()
     torch.cuda.synchronize()
 
     # rays per frame of this rank: primary + shadow (one per pixel, misses included: misc_kernel.cu:255)
@@ -330,9 +342,7 @@ def main():
     # hipEvent pairs bracket the four tracer kernels inside the timed loop (the roofline figure needs the
     # dominant kernel's live launch time); every other stage is timed in a separate, untimed pass below,
     # because ~40 event pairs per frame would themselves cost about 7 % of the frame.
-    tracers = ("trace_primary", "shadow_cull", "trace_shadow", "trace_dda")
     # events are recorded on the stream a kernel runs on
-    profiled = [c for rr in renderers for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else [])]
 
     def merged_prof():
         out = {}
@@ -556,6 +566,7 @@ def main():
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
         "stages_ms_per_step_alone_on_one_stream": alone,
+        "warmup_steps_run": warm,
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},
     }
     if args.stages_json:

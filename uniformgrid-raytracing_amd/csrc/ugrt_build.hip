@@ -552,10 +552,17 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_merge_narrow(const u32 *__res
 __global__ __launch_bounds__(64) void k_merge_wide(const u32 *__restrict__ nvals, const u32 *__restrict__ cstart,
 						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
 						    const u32 *__restrict__ wl, u32 C, WideBox wb,
-						    u32 *__restrict__ okeys, u32 *__restrict__ ovals)
+						    u32 *__restrict__ okeys, u32 *__restrict__ ovals,
+						    u32 *__restrict__ report_tail, const u32 *__restrict__ used,
+						    const u32 *__restrict__ status)
 {
 	__shared__ u32 s_n[MERGE_LDS];
 	const u32 lane = threadIdx.x;
+	// the last kernel of an asynchronous build completes its report (one copy then takes it to the host)
+	if (report_tail && blockIdx.x == 0 && lane == 0) {
+		report_tail[0] = *used;
+		report_tail[1] = *status;
+	}
 	const u32 W = d_wide_count(wb);
 	if (W == 0u)
 		return;
@@ -661,7 +668,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
 	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
 	u32 *rw = ctx->d_small + UGRT_DSMALL_RW + 2 * gi, *status = ctx->d_small + UGRT_DSMALL_STATUS;
-	u32 *report = ctx->d_small + UGRT_DSMALL_REPORT + 2 * gi;
+	u32 *report = ctx->d_small + UGRT_DSMALL_REPORT + 4 * gi;
 	hipLaunchKernelGGL(k_build_check, dim3(1), dim3(1), 0, st, (const u32 *)G.scan.p + (F - 1), capRn, capW, capR, active, rw,
 			   status, report);
 	UGRT_HIP(hipGetLastError());
@@ -705,7 +712,8 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 			   (const u32 *)cstart, (const u32 *)G.offset.p, (const u32 *)wsorted, wb, k0, v0);
 	u32 blocks = C < 256u * 32u ? C : 256u * 32u;
 	hipLaunchKernelGGL(k_merge_wide, dim3(blocks), dim3(64), 0, st, (const u32 *)v1, (const u32 *)cstart,
-			   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0);
+			   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0, report + 2,
+			   (const u32 *)used, (const u32 *)status);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
 	G.keys = k0;
@@ -713,9 +721,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	G.R = (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
 	G.r_exact = false;
 	G.active_cells = active;
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REPORT + 2 * gi, report, 8, hipMemcpyDeviceToHost, st));
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_CELLS_USED + gi, used, 4, hipMemcpyDeviceToHost, st));
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_STATUS, status, 4, hipMemcpyDeviceToHost, st));
+	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REPORT + 4 * gi, report, 16, hipMemcpyDeviceToHost, st));
 	G.async_pending = true;
 	G.valid = true;
 	return UGRT_OK;
@@ -729,15 +735,15 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	int rc;
 	const int gidx = (int)(&G - ctx->grid);
 	if (G.async_pending) { // what the previous asynchronous build of this grid reported (possibly a frame old)
-		G.est_rn = ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx];
-		G.est_w = ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx + 1];
+		G.est_rn = ctx->h_pinned[UGRT_PIN_REPORT + 4 * gidx];
+		G.est_w = ctx->h_pinned[UGRT_PIN_REPORT + 4 * gidx + 1];
 	}
 	// asynchronous when asked for, when this grid has been built before (an estimate exists), when no overflow is
 	// pending, and when the wide list fits the rank kernel
 	if (ctx->opt[UGRT_OPT_ASYNC_BUILD] == 1 && G.have_est && G.est_w <= 3000u && ctx->cfg.slabs == 1 &&
-	    ctx->h_pinned[UGRT_PIN_STATUS] == 0u && !ctx->overflow_seen)
+	    ugrt_reported_status(ctx) == 0u && !ctx->overflow_seen)
 		return build_common_async(ctx, G, F, C, ny, nz, ylo, yhi);
-	if (ctx->h_pinned[UGRT_PIN_STATUS] != 0u)
+	if (ugrt_reported_status(ctx) != 0u)
 		ctx->overflow_seen = true; // reported by ugrt_ctx_synchronize; until then every call waits and sizes exactly
 	G.async_pending = false;
 	G.valid = false;
@@ -771,8 +777,8 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	G.est_w = W;
 	G.have_est = true;
 	// (the slots an asynchronous build reports into: never older than this build)
-	ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx] = Rn;
-	ctx->h_pinned[UGRT_PIN_REPORT + 2 * gidx + 1] = W;
+	ctx->h_pinned[UGRT_PIN_REPORT + 4 * gidx] = Rn;
+	ctx->h_pinned[UGRT_PIN_REPORT + 4 * gidx + 1] = W;
 	// the sort goes key[0] -> key[1]; with wide triangles the merged lists are written back into key[0]
 	size_t rb1 = (size_t)(Rn ? Rn : 1) * 4, rb0 = W ? (size_t)(R ? R : 1) * 4 : rb1;
 	if ((rc = ugrt_buf_reserve(ctx, G.key[0], rb0)) || (rc = ugrt_buf_reserve(ctx, G.val[0], rb0)) ||
@@ -842,7 +848,8 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		}
 		u32 blocks = C < 256u * 32u ? C : 256u * 32u;
 		hipLaunchKernelGGL(k_merge_wide, dim3(blocks), dim3(64), 0, st, (const u32 *)v1, (const u32 *)cstart,
-				   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0);
+				   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0,
+				   (u32 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr);
 		UGRT_HIP(hipGetLastError());
 		G.keys = k0;
 		G.vals = v0;

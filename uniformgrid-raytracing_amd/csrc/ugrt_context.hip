@@ -228,10 +228,12 @@ extern "C" int ugrt_ctx_synchronize(ugrt_ctx *ctx)
 	// asynchronous builds / shadow passes: a count that did not fit the capacity it was given (sized by the call
 	// before) left that call's results incomplete.  Reported once; the next build and shadow pass run in the
 	// synchronous form and size the buffers exactly.
-	if (ctx->h_pinned[UGRT_PIN_STATUS] != 0u || ctx->overflow_seen) {
-		const unsigned bits = ctx->h_pinned[UGRT_PIN_STATUS];
+	if (ugrt_reported_status(ctx) != 0u || ctx->overflow_seen) {
+		const unsigned bits = ugrt_reported_status(ctx);
 		ctx->overflow_seen = false;
-		ctx->h_pinned[UGRT_PIN_STATUS] = 0u;
+		for (int g = 0; g < 3; g++)
+			ctx->h_pinned[UGRT_PIN_REPORT + 4 * g + 3] = 0u;
+		ctx->h_pinned[UGRT_PIN_SHADOW + 2] = 0u;
 		UGRT_HIP(hipMemsetAsync(ctx->d_small + UGRT_DSMALL_STATUS, 0, 4, ctx->stream));
 		UGRT_HIP(hipStreamSynchronize(ctx->stream));
 		for (int g = 0; g < 3; g++)
@@ -310,10 +312,10 @@ extern "C" int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out)
 	out->d_offset = (unsigned *)G.offset.p;
 	out->total_refs = G.R;
 	if (!G.r_exact) // asynchronous build: what the build reported (final once the stream has been synchronised)
-		out->total_refs = (unsigned)(ctx->h_pinned[UGRT_PIN_REPORT + 2 * which] +
-					     G.active_cells * ctx->h_pinned[UGRT_PIN_REPORT + 2 * which + 1]);
+		out->total_refs = (unsigned)(ctx->h_pinned[UGRT_PIN_REPORT + 4 * which] +
+					     G.active_cells * ctx->h_pinned[UGRT_PIN_REPORT + 4 * which + 1]);
 	out->num_cells = G.C;
-	out->cells_used = ctx->h_pinned[UGRT_PIN_CELLS_USED + which];
+	out->cells_used = G.r_exact ? ctx->h_pinned[UGRT_PIN_CELLS_USED + which] : ctx->h_pinned[UGRT_PIN_REPORT + 4 * which + 2];
 	return UGRT_OK;
 }
 

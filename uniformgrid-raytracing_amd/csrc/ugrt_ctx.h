@@ -74,8 +74,10 @@ struct Grid {
 #define UGRT_DSMALL_TEX 32         // [100] the 5x5x4 direction table
 #define UGRT_DSMALL_DDA 132        // u64 [UGRT_DDA_STATS] work counters of the DDA
 #define UGRT_DSMALL_RW 236         // [3][2] checked {narrow references, wide triangles} of an asynchronous build
-#define UGRT_DSMALL_REPORT 242     // [3][2] the same as found (what the next build is sized by)
-#define UGRT_DSMALL_SHADOW 248     // [8] asynchronous shadow tracer: checked and reported counts
+#define UGRT_DSMALL_REPORT 242     // [3][4] report of a grid's asynchronous build: {narrow references, wide triangles} as
+                                   // found (what the next build is sized by), cells used, the status word at its end
+#define UGRT_DSMALL_SHADOW 254     // [10] shadow tracer: {pairs, beams} as checked, then its report: {pairs, beams} as
+                                   // found, status word, pad, the two u64 work counters at the start of the exact pass
 #define UGRT_DSMALL_PRIMARY 264    // u64 [UGRT_PRIMARY_STATS] work counters of the primary tracer (FLAG_COUNT_WORK)
 #define UGRT_DSMALL_WORDS (132 + 104 + 28 + 32)
 // layout of ugrt_ctx::h_pinned (u32 words of pinned host memory for small read-backs)
@@ -85,10 +87,9 @@ struct Grid {
 #define UGRT_PIN_PAIRS 10       // candidate pairs of the shadow pass
 #define UGRT_PIN_CHUNKS 11      // chunks of ugrt_sort_rays
 #define UGRT_PIN_BEAMS 12       // beams of the shadow pass
-#define UGRT_PIN_SHADOW_WORK 14 // u64 [2]: copy of UGRT_DSMALL_SHADOW_WORK
-#define UGRT_PIN_STATUS 20      // copy of UGRT_DSMALL_STATUS
-#define UGRT_PIN_REPORT 22      // [3][2] copy of UGRT_DSMALL_REPORT
-#define UGRT_PIN_SHADOW 30      // {pairs, beams} of the last asynchronous shadow pass
+#define UGRT_PIN_SHADOW_WORK (UGRT_PIN_SHADOW + 4) // u64 [2]: cull tests, staged candidates
+#define UGRT_PIN_REPORT 32      // [3][4] copies of UGRT_DSMALL_REPORT (one copy per build)
+#define UGRT_PIN_SHADOW 44      // [8] copy of the shadow tracer's report (UGRT_DSMALL_SHADOW + 2 ...)
 #define UGRT_PIN_WORDS 64
 #define UGRT_STATUS_BUILD_OVERFLOW 1u
 #define UGRT_STATUS_PAIR_OVERFLOW 2u
@@ -96,7 +97,7 @@ struct Grid {
 #define UGRT_DDA_STATS 46
 #define UGRT_PRIMARY_STATS 16
 static_assert(UGRT_DSMALL_DDA + 2 * UGRT_DDA_STATS <= UGRT_DSMALL_RW, "the DDA's counters run into the build counts");
-static_assert(UGRT_DSMALL_SHADOW + 8 <= UGRT_DSMALL_PRIMARY && UGRT_DSMALL_PRIMARY + 2 * UGRT_PRIMARY_STATS <= UGRT_DSMALL_WORDS && UGRT_PIN_SHADOW + 2 <= UGRT_PIN_WORDS, "scratch layout");
+static_assert(UGRT_DSMALL_REPORT + 12 <= UGRT_DSMALL_SHADOW && UGRT_DSMALL_SHADOW + 10 <= UGRT_DSMALL_PRIMARY && UGRT_DSMALL_PRIMARY + 2 * UGRT_PRIMARY_STATS <= UGRT_DSMALL_WORDS && UGRT_PIN_SHADOW + 8 <= UGRT_PIN_WORDS && UGRT_PIN_REPORT + 12 <= UGRT_PIN_SHADOW, "scratch layout");
 
 struct ProfPair {
 	hipEvent_t a, b;
@@ -115,6 +116,7 @@ struct ugrt_ctx {
 	Grid grid[3];
 	DevBuf temp;                  // rocPRIM temporary storage
 	DevBuf rs_state, rs_tmp[2];   // own radix sort: histograms + tickets + look-back words, ping-pong buffers
+	int rs_flip = 0;              // which of rs_state's two histogram blocks the next sort uses (the other one is cleared by it)
 	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
 	// gather ONE record per reference instead of 3 indices + 3 vertices
 	DevBuf trirec;
@@ -161,6 +163,12 @@ int ugrt_buf_reserve(ugrt_ctx *ctx, DevBuf &b, size_t bytes);
 int ugrt_slab_union(ugrt_ctx *ctx, const u32 *d_span, const u32 *d_offset, u32 C, u32 slabs, const u32 **uspan,
 		    const u32 **uoffset);
 float *ugrt_ctx_tex(ugrt_ctx *ctx); // device copy of the 5x5x4 direction table
+// status words the asynchronous calls have reported so far (each report carries the device's word as it stood then)
+static inline u32 ugrt_reported_status(const ugrt_ctx *ctx)
+{
+	const u32 *p = ctx->h_pinned;
+	return p[UGRT_PIN_REPORT + 3] | p[UGRT_PIN_REPORT + 7] | p[UGRT_PIN_REPORT + 11] | p[UGRT_PIN_SHADOW + 2];
+}
 static inline u32 *ugrt_wide_counter(ugrt_ctx *ctx) { return ctx->d_small + UGRT_DSMALL_WIDE; }
 void ugrt_prof_begin(ugrt_ctx *ctx, int stage);
 void ugrt_prof_end(ugrt_ctx *ctx, int stage);

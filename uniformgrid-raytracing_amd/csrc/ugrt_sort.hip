@@ -35,9 +35,20 @@
 
 // digit histograms of all passes in one read of the keys
 // (n_dev: the number of pairs when only the device knows it; n is then the capacity the launch was sized for)
+// It also clears what the kernels after it expect to be zero, so that a sort needs no fill: the look-back words of
+// this sort's passes (`look`) and the histogram + ticket block of the NEXT sort (`next_head`; the two blocks of the
+// state alternate from sort to sort, both on the context's stream).
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, int passes, u32 end_bit,
-							 u32 *__restrict__ hist, const u32 *__restrict__ n_dev)
+							 u32 *__restrict__ hist, const u32 *__restrict__ n_dev,
+							 u32 *__restrict__ next_head, u32 head_words, u32 *__restrict__ look,
+							 u32 look_words)
 {
+	for (u32 i = blockIdx.x * RS_THREADS + threadIdx.x; i < head_words + look_words; i += gridDim.x * RS_THREADS) {
+		if (i < head_words)
+			next_head[i] = 0u;
+		else
+			look[i - head_words] = 0u;
+	}
 	if (n_dev)
 		n = *n_dev < n ? *n_dev : n;
 	__shared__ u32 s_h[RS_MAXPASS][RS_BINS];
@@ -265,22 +276,30 @@ int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin
 	const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
 	hipStream_t st = ctx->stream;
 	int rc;
-	// state: [passes][256] histograms, [passes] tickets (padded to 256), per pass [tiles][256] tile counts and
-	// [chunks][256] chunk sums
+	// state: two blocks of {[RS_MAXPASS][256] histograms, [256] tickets} that alternate from sort to sort, then per
+	// pass [tiles][256] tile counts and [chunks][256] chunk sums
 	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
 	const size_t per_pass = (size_t)(tiles + chunks) * RS_BINS;
-	const size_t words = (size_t)passes * RS_BINS + RS_BINS + (size_t)passes * per_pass;
+	const size_t head = (size_t)RS_MAXPASS * RS_BINS + RS_BINS;
+	const size_t words = 2 * head + (size_t)passes * per_pass;
+	const void *before = ctx->rs_state.p;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->rs_state, words * 4)))
 		return rc;
 	if (passes > 1) {
 		if ((rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[0], n * 4)) || (rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[1], n * 4)))
 			return rc;
 	}
-	u32 *hist = (u32 *)ctx->rs_state.p, *ticket = hist + (size_t)passes * RS_BINS, *look = ticket + RS_BINS;
-	UGRT_HIP(hipMemsetAsync(hist, 0, words * 4, st));
+	if (ctx->rs_state.p != before) { // a new allocation: nothing has cleared the first block yet
+		UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, 2 * head * 4, st));
+		ctx->rs_flip = 0;
+	}
+	u32 *hist = (u32 *)ctx->rs_state.p + (size_t)ctx->rs_flip * head, *ticket = hist + (size_t)RS_MAXPASS * RS_BINS;
+	u32 *next_head = (u32 *)ctx->rs_state.p + (size_t)(ctx->rs_flip ^ 1) * head, *look = (u32 *)ctx->rs_state.p + 2 * head;
+	ctx->rs_flip ^= 1;
 	u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
 	hblocks = hblocks > 256u ? 256u : hblocks;
-	hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, passes, (u32)end_bit, hist, n_dev);
+	hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, passes, (u32)end_bit, hist, n_dev,
+			   next_head, (u32)head, look, (u32)((size_t)passes * per_pass));
 	UGRT_HIP(hipGetLastError());
 	const u32 *ki = kin, *vi = vin;
 	for (int p = 0; p < passes; p++) {

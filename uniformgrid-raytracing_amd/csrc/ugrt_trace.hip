@@ -1152,10 +1152,19 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      const float *__restrict__ ray_direction_list,
 						      int *__restrict__ is_shadowed, const u32 *__restrict__ ray_pixels,
 						      const float *__restrict__ cmPt, u32 XSEG, u32 *__restrict__ sub_done,
-						      u32 nsubmax, const float4 *__restrict__ sray, u32 item_cap)
+						      u32 nsubmax, const float4 *__restrict__ sray, u32 item_cap,
+						      u32 *__restrict__ report, const u32 *__restrict__ status,
+						      const unsigned long long *__restrict__ work)
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
 	const int lane = threadIdx.x;
+	// every kernel that raises a status bit or counts work has finished: complete the pass's report
+	if (blockIdx.x == 0 && lane == 0) {
+		report[2] = *status;
+		report[3] = 0u;
+		reinterpret_cast<unsigned long long *>(report + 4)[0] = work[0];
+		reinterpret_cast<unsigned long long *>(report + 4)[1] = work[1];
+	}
 	u32 total = xincl[G - 1];
 	if (total > item_cap)
 		total = item_cap; // (asynchronous form: a list cut at its estimated capacity is flagged by k_pair_items)
@@ -1411,9 +1420,9 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		ctx->est_pairs = ctx->h_pinned[UGRT_PIN_SHADOW];
 		ctx->est_beams = ctx->h_pinned[UGRT_PIN_SHADOW + 1];
 	}
-	const bool async = ctx->opt[UGRT_OPT_ASYNC_BUILD] == 1 && ctx->have_shadow_est && ctx->h_pinned[UGRT_PIN_STATUS] == 0u &&
+	const bool async = ctx->opt[UGRT_OPT_ASYNC_BUILD] == 1 && ctx->have_shadow_est && ugrt_reported_status(ctx) == 0u &&
 			   !ctx->overflow_seen;
-	if (!async && ctx->h_pinned[UGRT_PIN_STATUS] != 0u)
+	if (!async && ugrt_reported_status(ctx) != 0u)
 		ctx->overflow_seen = true;
 	u32 P = 0, G = 0, Gcap = 0, xcap = 0;
 	const u32 *pgp = nullptr; // device counts (asynchronous form)
@@ -1461,8 +1470,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			hipLaunchKernelGGL(k_pair_check, dim3(1), dim3(1), 0, st, (const u32 *)pcount, (u32)cap,
 					   (const u32 *)(gincl + (C - 1)), G, pg, status, report);
 			UGRT_HIP(hipGetLastError());
-			UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW, report, 8, hipMemcpyDeviceToHost, st));
-			pgp = pg;
+			pgp = pg; // (the report travels to the host with the copy behind the exact pass)
 			const size_t lp = (size_t)ctx->est_pairs + ctx->est_pairs / 4 + 65536;
 			P = (u32)(lp < cap ? lp : cap); // launch size of the per-pair kernels
 			xcap = (ctx->est_beams + ctx->est_beams / 4u + 64u + P / XSEG) * (beam / 64u);
@@ -1529,9 +1537,6 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		iseg1 = iseg0;
 		isub1 = isub0;
 	}
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW_WORK, wcnt, 16, hipMemcpyDeviceToHost, st)); // read by ugrt_stats_get
-	if (async)
-		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_STATUS, status, 4, hipMemcpyDeviceToHost, st));
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
@@ -1540,15 +1545,21 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p, xcap);
+				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt);
 	else
 		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p, xcap);
+				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
+	// ONE copy per pass: {pairs, beams} as found (asynchronous form: what the next pass is sized by; the waiting form
+	// knows them already and keeps the host's words), the status word, the work counters (ugrt_stats_get)
+	if (async)
+		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW, report, 32, hipMemcpyDeviceToHost, st));
+	else
+		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW + 2, report + 2, 24, hipMemcpyDeviceToHost, st));
 	return UGRT_OK;
 }
 

@@ -205,6 +205,8 @@ def main():
                     help="launch-shape option for every context (ugrt_ctx_set_option), e.g. dda_kernel=1")
     ap.add_argument("--uniform-grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
                     help="cells of the bounce's uniform grid (A13 is this repo's own spec: any resolution gives the same hits)")
+    ap.add_argument("--balance-rounds", type=int, default=4,
+                    help="N > 1: rounds of timing the bands and moving their boundaries before the measurement (0 = equal bands)")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
@@ -248,7 +250,6 @@ def main():
     else:
         W, H = parallel.weak_scaling_resolution(world)
     nby = H // 8
-    rows = parallel.band_rows(rank, world, nby)
     lg, udims = (128, 128), (128, 128, 64)
     if args.uniform_grid:
         udims = tuple(args.uniform_grid)
@@ -257,31 +258,76 @@ def main():
     setup = ugrt.FrameSetup.from_scene(s)
     # the renderer is the only writer of the vertex array (ugrt_animate): triangle records survive between builds
     flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | (0 if args.no_static_geometry else ugrt.FLAG_STATIC_GEOMETRY)
-    ctx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
-    shards = parallel.GridShards(dist, torch, ctx.device, rank, world, host_staging=rehearse) \
-        if args.shard_builds else None
-    r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
-                      overlap=not args.no_overlap and shards is None, shards=shards, helper_thread=args.waiting_builds)
-    renderers = [r]
-    for i in range(1, max(1, args.frames_in_flight)):
-        with torch.cuda.stream(torch.cuda.Stream(ctx.device)):
-            cx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
-            renderers.append(ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
-                                           overlap=not args.no_overlap and shards is None, shards=shards,
-                                           helper_thread=args.waiting_builds))
-            renderers[-1]._stream = torch.cuda.current_stream(ctx.device)
     opts = ([] if args.waiting_builds else ["async_build=1"]) + args.opt
-    for kv in opts:
-        k, v = kv.split("=")
-        for rr in renderers:
-            for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
-                c.set_option(k, int(v))
-    gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world, host_staging=rehearse)
-
     reflect = not args.no_reflect
-    if args.animate:
-        for rr in renderers:
-            rr.init_orig_list(s["animated_size"], s["animated_offset"])
+    device = torch.device("cuda", local)
+    shards = parallel.GridShards(dist, torch, device, rank, world, host_staging=rehearse) if args.shard_builds else None
+
+    def make_renderers(rows):
+        """One renderer per frame in flight for this rank's band `rows`, each with its own contexts and stream."""
+        out = []
+        for i in range(max(1, args.frames_in_flight)):
+            stream = torch.cuda.Stream(device) if i else None
+            with torch.cuda.stream(stream):
+                cx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
+                rr = ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
+                                   overlap=not args.no_overlap and shards is None, shards=shards,
+                                   helper_thread=args.waiting_builds)
+            if stream is not None:
+                rr._stream = stream
+            for kv in opts:
+                k, v = kv.split("=")
+                for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
+                    c.set_option(k, int(v))
+            if args.animate:
+                rr.init_orig_list(s["animated_size"], s["animated_offset"])
+            out.append(rr)
+        return out
+
+    def frames_ms(rs, frames):
+        """ms per frame of `frames` pipelined frames on the renderers `rs` (no gather): this rank's band alone."""
+        for rr in rs:
+            rr.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(frames):
+            rr = rs[k % len(rs)]
+            with torch.cuda.stream(getattr(rr, "_stream", None)):
+                rr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+        for rr in rs:
+            rr.synchronize()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / frames * 1e3
+
+    # Bands: SURVEY.md 8(e) shards the image by tile rows and the slowest rank sets the frame time (8 equal bands of
+    # the 5432x3056 frame take 1.09 ... 1.71 ms, tools/band_balance.py).  Before the measurement the ranks time their
+    # bands, all-gather the times and move the boundaries (parallel.balanced_bounds: a pure function of the gathered
+    # times, so every rank arrives at the same bands); at most --balance-rounds times.
+    bounds = parallel.equal_bounds(world, nby)
+    balance_log = []
+    if world > 1 and args.balance_rounds > 0 and shards is None:
+        for _ in range(args.balance_rounds):
+            rs = make_renderers((bounds[rank], bounds[rank + 1]))
+            frames_ms(rs, 6)
+            mine = frames_ms(rs, 12)
+            for rr in rs:
+                rr.close()
+            del rs
+            times = [None] * world
+            dist.all_gather_object(times, float(mine))
+            balance_log.append({"bounds": list(bounds), "band_ms": [round(t, 4) for t in times]})
+            if max(times) < 1.03 * (sum(times) / world):
+                break
+            new_bounds = parallel.balanced_bounds(bounds, times)
+            if new_bounds == bounds:
+                break
+            bounds = new_bounds
+    rows = (bounds[rank], bounds[rank + 1])
+    renderers = make_renderers(rows)
+    r = renderers[0]
+    ctx = r.ctx
+    gather = parallel.BandGather(dist, torch, ctx.device, W, nby, rank, world, host_staging=rehearse, bounds=bounds)
+
     frame_no = [0]
 
     turn = [0]
@@ -567,6 +613,8 @@ def main():
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
         "stages_ms_per_step_alone_on_one_stream": alone,
         "warmup_steps_run": warm,
+        "band_bounds_tile_rows": list(bounds) if world > 1 else None,
+        "band_balance_rounds": balance_log if world > 1 else None,
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},
     }
     if args.stages_json:

@@ -51,6 +51,78 @@ def _worker(rank, world, port, W, H, out_path):
         dist.destroy_process_group()
 
 
+def _worker_balanced(rank, world, port, W, H, out_path):
+    """The band balancing of bench.py: the ranks all-gather what their bands cost, derive the same new boundaries
+    from it (no broadcast), render the UNEQUAL bands and gather them."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+
+    import oracle_lib as O
+    import ugrt
+    from ugrt import parallel
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        O.set_threads(2)
+        s = ugrt.scenes.hall(scale=0.05)
+        setup = ugrt.FrameSetup.from_scene(s)
+        nby = H // 8
+        bounds = parallel.equal_bounds(world, nby)
+        times = [None] * world
+        dist.all_gather_object(times, [3.0, 1.0][rank])  # rank 0's band costs three times rank 1's
+        bounds = parallel.balanced_bounds(bounds, times)
+        every = [None] * world
+        dist.all_gather_object(every, bounds)
+        assert every[0] == every[1] and bounds[1] < nby // 2, every
+        rows = (bounds[rank], bounds[rank + 1])
+        fr = O.frame(s, setup, W, H, rows=rows, light_grid=(32, 32), all_chunks=True)
+        image = torch.from_numpy(fr["image"].copy())
+        g = parallel.BandGather(dist, torch, torch.device("cpu"), W, nby, rank, world, bounds=bounds)
+        g.gather(image)
+        g.finish()
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, image.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_balanced_bands(tmp_path, ugrt, O):
+    import torch.multiprocessing as mp
+
+    W, H = 128, 136
+    out = str(tmp_path / "img.npy")
+    mp.spawn(_worker_balanced, args=(2, _free_port(), W, H, out), nprocs=2, join=True)
+    got = np.load(out)
+    s = ugrt.scenes.hall(scale=0.05)
+    want = O.frame(s, ugrt.FrameSetup.from_scene(s), W, H, light_grid=(32, 32), all_chunks=True)["image"]
+    np.testing.assert_array_equal(got, want)
+
+
+def test_balanced_bounds_is_a_partition_and_evens_out_a_cost_profile(ugrt):
+    from ugrt import parallel
+
+    rng = np.random.default_rng(5)
+    for world, nby in ((2, 17), (4, 270), (8, 382), (8, 9)):
+        cost = rng.uniform(0.2, 1.0, nby) + 3.0 * np.exp(-((np.arange(nby) - 0.3 * nby) / (0.08 * nby)) ** 2)
+        fixed = 0.3 * cost.sum() / world  # what every rank pays whatever its band
+        bounds = parallel.equal_bounds(world, nby)
+        spread = []
+        for _ in range(6):
+            times = [fixed + cost[bounds[r]:bounds[r + 1]].sum() for r in range(world)]
+            spread.append(max(times) / (sum(times) / world))
+            bounds = parallel.balanced_bounds(bounds, times)
+            assert bounds[0] == 0 and bounds[-1] == nby and all(b > a for a, b in zip(bounds, bounds[1:])), bounds
+        assert spread[-1] <= spread[0] + 1e-9
+        if nby >= 32 * world:
+            assert spread[-1] < 1.08, spread  # (the model ignores the fixed part: it under-corrects and converges)
+    assert parallel.balanced_bounds([0, 1, 2, 3], [1.0, 5.0, 1.0]) == [0, 1, 2, 3]  # one row each: nothing to move
+
+
 @pytest.mark.parametrize("H", [128, 136])  # 16 tile rows (even split) and 17 (uneven bands)
 def test_two_rank_band_gather(tmp_path, ugrt, O, H):
     import torch.multiprocessing as mp

@@ -99,3 +99,6 @@ def test_bench_two_ranks_on_one_gpu_gather_the_right_image(extra):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["verified_against_single_context_frame"] is True
+    if "--shard-builds" not in extra:  # the bands were timed and moved before the measurement: still a partition
+        b = line["band_bounds_tile_rows"]
+        assert b[0] == 0 and len(b) == 3 and b[0] < b[1] < b[2] and line["band_balance_rounds"], line

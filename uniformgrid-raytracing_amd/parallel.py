@@ -14,6 +14,38 @@ def band_rows(rank, world, nby):
     return (rank * nby) // world, ((rank + 1) * nby) // world
 
 
+def equal_bounds(world, nby):
+    """Band boundaries [b_0 = 0, ..., b_world = nby] of band_rows."""
+    return [band_rows(r, world, nby)[0] for r in range(world)] + [nby]
+
+
+def balanced_bounds(bounds, times, fixed=0.0):
+    """New band boundaries from the frame times the ranks measured on the current ones (SURVEY.md 8e shards by
+    tile rows; which rows is free).  A band's time is taken as `fixed` (what every rank pays whatever its band:
+    the replicated light and uniform grid builds) + a cost spread evenly over its tile rows; the new boundaries
+    cut the accumulated cost into equal parts.  Every band keeps at least one row; the result is a pure function
+    of its arguments, so ranks that all-gather `times` agree on it without a broadcast."""
+    world = len(times)
+    assert len(bounds) == world + 1 and bounds[0] == 0
+    nby = bounds[-1]
+    dens = []
+    for r in range(world):
+        rows = bounds[r + 1] - bounds[r]
+        dens += [max(times[r] - fixed, 1e-9) / rows] * rows
+    cum = np.concatenate([[0.0], np.cumsum(dens)])
+    out = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        b = int(np.searchsorted(cum, target, side="left"))
+        # the nearer of the two rows around the target
+        if b > 0 and abs(cum[b - 1] - target) <= abs(cum[min(b, nby)] - target):
+            b -= 1
+        b = max(b, out[-1] + 1)
+        b = min(b, nby - (world - r))
+        out.append(b)
+    return out + [nby]
+
+
 def weak_scaling_resolution(world, base=(1920, 1080)):
     """Same view, more pixels: area scales with `world`, aspect stays 16:9, multiples of 8.
     1 -> 1920x1080, 2 -> 2720x1528, 4 -> 3840x2160 (BASELINE config 4), 8 -> 5432x3056."""
@@ -26,13 +58,14 @@ def weak_scaling_resolution(world, base=(1920, 1080)):
 class BandGather:
     """Gathers every rank's RGB band into rank 0's full image with one collective."""
 
-    def __init__(self, dist, torch, device, width, nby, rank, world, host_staging=False):
+    def __init__(self, dist, torch, device, width, nby, rank, world, host_staging=False, bounds=None):
         self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
         self.image_device = device
         if host_staging:  # backends without device-tensor gather (gloo): stage the bands through the host
             device = torch.device("cpu")
         self.width, self.nby = width, nby
-        self.bands = [band_rows(r, world, nby) for r in range(world)]
+        bounds = bounds if bounds is not None else equal_bounds(world, nby)
+        self.bands = [(bounds[r], bounds[r + 1]) for r in range(world)]
         self.max_bytes = max(e - b for b, e in self.bands) * 8 * width * 3
         self.send = torch.zeros(self.max_bytes, dtype=torch.uint8, device=device)
         self.recv = ([torch.zeros(self.max_bytes, dtype=torch.uint8, device=device) for _ in range(world)]

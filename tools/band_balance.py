@@ -46,7 +46,15 @@ print("1 GPU 1920x1080: %.3f ms" % base, flush=True)
 for N in [int(a) for a in sys.argv[1:]] or [2, 4, 8]:
     W, H = par.weak_scaling_resolution(N)
     nby = H // 8
-    ts = [band_ms(W, H, par.band_rows(r, N, nby)) for r in range(N)]
-    out[N] = {"resolution": [W, H], "band_ms": [round(t, 3) for t in ts], "efficiency_bound": round(base / max(ts), 3)}
-    print(N, json.dumps(out[N]), flush=True)
+    bounds = par.equal_bounds(N, nby)
+    rounds = []
+    for it in range(4):  # what bench.py does before its measurement, one band at a time
+        ts = [band_ms(W, H, (bounds[r], bounds[r + 1])) for r in range(N)]
+        rounds.append({"bounds": list(bounds), "band_ms": [round(t, 3) for t in ts], "slowest_over_mean": round(max(ts) / (sum(ts) / N), 3),
+                       "efficiency_bound": round(base / max(ts), 3)})
+        print(N, json.dumps(rounds[-1]), flush=True)
+        if max(ts) < 1.03 * sum(ts) / N:
+            break
+        bounds = par.balanced_bounds(bounds, ts)
+    out[N] = {"resolution": [W, H], "rounds": rounds}
 json.dump({"one_gpu_ms": round(base, 3), "bands": out}, open("gpurun_out/band_balance.json", "w"), indent=1)

@@ -15,6 +15,7 @@ and grows with N at fixed 16:9 aspect (weak scaling; N = 4 is configs[3]'s 3840x
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -382,6 +383,8 @@ def main():
     if reflect and not args.animate:
         assert st[5] == active, (st[5], active)
     del cr, cctx
+    gc.collect()  # the counting context's buffers are freed HERE (hipFree synchronises the device), not by a collection inside the timed region
+    torch.cuda.synchronize()
     abytes = algorithmic_bytes(torch, ugrt, ctx, r, dda_counts)
 
     # ---- timed region: exactly K steps between barrier + synchronize pairs -------------------

@@ -590,6 +590,33 @@ def test_depth_layers_ties_and_grazing_triangles(ugrt, O, torch):
     np.testing.assert_array_equal(cr.intersect_id.cpu().numpy(), ids)
 
 
+@pytest.mark.parametrize("seed,ntri,W,H", [(1, 600, 128, 96), (2, 6000, 160, 120), (3, 40000, 192, 104), (4, 2500, 64, 64)])
+def test_random_soups(ugrt, O, torch, seed, ntri, W, H):
+    """Random triangle soups with sizes over three decades (a few that fill the view, many of a pixel or less,
+    needles), seen from INSIDE the cloud (triangles on every side of the eye, also behind it: Q1), light inside as
+    well: every cull (tile and quadrant boxes, depth bound, beam boxes, bundle boxes of the bounce) sees inputs no
+    modelled scene has.  The frame is the oracle's, bit for bit."""
+    s0 = scene(ugrt, "cornell")
+    rng = np.random.default_rng(7000 + seed)
+    size = np.exp(rng.uniform(np.log(0.5), np.log(400.0), ntri))
+    size[rng.random(ntri) < 0.01] = 900.0
+    c = rng.uniform(-100.0, 656.0, (ntri, 3))
+    tri = c[:, None, :] + rng.normal(0.0, 1.0, (ntri, 3, 3)) * size[:, None, None] * 0.5
+    needles = rng.random(ntri) < 0.05
+    tri[needles, 2] = tri[needles, 0] + (tri[needles, 1] - tri[needles, 0]) * 0.5 + rng.normal(0, 1e-3, (int(needles.sum()), 3))
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    faces = np.arange(3 * ntri, dtype=np.int32).reshape(-1, 3)
+    s = dict(s0)
+    s.update(verts=verts, faces=faces, matidx=rng.integers(0, len(s0["mat_list"]), ntri).astype(np.int32))
+    eye = rng.uniform(150.0, 400.0, 3)
+    cam = dict(eye=tuple(eye), look=tuple(eye + rng.normal(0, 1, 3)), up=(0, 1, 0), near=1.0, far=3000.0)
+    light = dict(eye=tuple(rng.uniform(100.0, 450.0, 3)), look=tuple(rng.uniform(100.0, 450.0, 3)), up=(0, 0, 1), near=1.0,
+                 far=3000.0)
+    setup = ugrt.FrameSetup(cam, light, tuple(rng.uniform(100.0, 450.0, 3)))
+    want = _frame_equals_oracle(ugrt, O, s, setup, W, H, (32, 32), (16, 16, 8))
+    assert (want["mat_ids"] >= 0).sum() > 0.1 * W * H
+
+
 def test_deferred_chunk_count_and_options(ugrt, O, torch):
     """ugrt_sort_rays without the read-back: the count fetched later equals the synchronous one, and the shadow
     tracer fed UGRT_CHUNKS_ON_DEVICE produces the same flags, in the reference's launch-capped mode and with

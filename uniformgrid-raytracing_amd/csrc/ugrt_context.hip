@@ -164,6 +164,7 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->tbcnt);
 	buf_free(ctx->sitem);
 	buf_free(ctx->citem);
+	buf_free(ctx->pseg);
 	buf_free(ctx->sray);
 	if (ctx->h_pinned)
 		(void)hipHostFree(ctx->h_pinned);

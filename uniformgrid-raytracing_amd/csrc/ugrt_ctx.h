@@ -131,7 +131,8 @@ struct ugrt_ctx {
 	DevBuf skey[2], sval[2], sdesc, sstart, scnt, sbase; // shadow tracer: re-grouped rays, beams, counts
 	DevBuf tkey[2], tval[2], tbcnt;                      // shadow tracer: candidate pairs, runs per beam
 	DevBuf sray;                                         // shadow tracer: rebuilt rays {direction, distance}, beam order
-	DevBuf citem;                                        // shadow tracer: light cell of every cull item
+	DevBuf citem;                                        // shadow tracer: the cull items (CullItem table)
+	DevBuf pseg;                                         // shadow tracer: cursors of the cull pass's output segments
 	DevBuf sitem;                                        // shadow tracer: exact-pass item list (segment, beam|sub) x2
 	u32 *h_pinned = nullptr; // pinned host words for small read-backs (UGRT_PIN_*)
 	u32 *d_small = nullptr;  // device scratch words (UGRT_DSMALL_*)

@@ -653,7 +653,9 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 //   3. the pair list is sorted by beam (rocPRIM), and
 //   4. EXACT pass, lane = ray: each beam runs the reference's per-ray test on its own short list.
 // The cull is conservative with margins far above fp32 rounding, so the flags do not change.
+#ifndef GCHUNK
 #define GCHUNK 32u  // beams a cull work item streams past its 64 triangles
+#endif
 
 struct GBox { // one beam (re-grouped rays of one light cell)
 	float cx, cy, cz; // centre of the direction box
@@ -935,19 +937,95 @@ __device__ __forceinline__ void d_flush_pairs(const u32 *buf_beam, const u32 *bu
 	__syncthreads();
 }
 
-// light cell of every cull item (the first CULL_TABLE of them; a frame has some 10^4): one load at the head of
-// an item instead of a search whose probes all miss the L1 when 8192 waves start together
+// The cull pass appends its pairs through PAIR_SEGS cursors instead of one: every wave ends with an append, and 10 k
+// atomics on ONE word take 12 ns each -- 0.12 ms, the whole kernel (per-wave cycle stamps: a third of a wave's time
+// went by in the appends).  Wave w appends to segment w % PAIR_SEGS of the staging arrays (cursors 256 B apart);
+// k_pair_compact then moves the segments together and leaves the total where the single cursor used to be.  A segment
+// that ran over reports a total that no buffer of this size could hold, so the caller's overflow handling applies.
+#define PAIR_SEGS 64u
+#define PAIR_SEG_STRIDE 64u // words between two cursors
+
+__global__ __launch_bounds__(256) void k_pair_compact(const u32 *__restrict__ segcnt, u32 segcap,
+						       const u32 *__restrict__ sbeam, const u32 *__restrict__ stri,
+						       u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri,
+						       u32 *__restrict__ pair_count)
+{
+	__shared__ u32 s_cnt[PAIR_SEGS], s_base[PAIR_SEGS];
+	__shared__ u32 s_over;
+	if (threadIdx.x == 0)
+		s_over = 0u;
+	__syncthreads();
+	if (threadIdx.x < PAIR_SEGS) {
+		const u32 c = segcnt[threadIdx.x * PAIR_SEG_STRIDE];
+		if (c > segcap)
+			atomicMax(&s_over, c);
+		s_cnt[threadIdx.x] = c < segcap ? c : segcap;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		u32 acc = 0;
+		for (u32 k = 0; k < PAIR_SEGS; k++) {
+			s_base[k] = acc;
+			acc += s_cnt[k];
+		}
+		if (blockIdx.x == 0) {
+			const unsigned long long worst = (unsigned long long)s_over * PAIR_SEGS;
+			pair_count[0] = s_over ? (worst > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)worst) : acc;
+		}
+	}
+	__syncthreads();
+	const u32 seg = blockIdx.x % PAIR_SEGS, part = blockIdx.x / PAIR_SEGS, parts = gridDim.x / PAIR_SEGS;
+	const u32 n = s_cnt[seg], base = s_base[seg];
+	const size_t src = (size_t)seg * segcap;
+	for (u32 i = part * 256u + threadIdx.x; i < n; i += parts * 256u) {
+		pair_beam[base + i] = sbeam[src + i];
+		pair_tri[base + i] = stri[src + i];
+	}
+}
+
+// A cull item = (light cell, batch of 64 of its triangles, chunk of GCHUNK of its beams), as the kernel needs it:
+// where the batch's ids start, how many there are, the first beam box and the number of boxes.
+struct CullItem {
+	u32 ref_base, cnt, gfirst, gcount;
+};
+
+__device__ __forceinline__ CullItem d_cull_item(const u32 *__restrict__ iincl, const u32 *__restrict__ gincl,
+						 const u32 *__restrict__ span, const u32 *__restrict__ offset, u32 C, u32 it)
+{
+	const u32 c = d_find_cell(iincl, C, it);
+	const u32 sp = span[c];
+	const u32 nb = (sp + 63u) / 64u;
+	const u32 ngrp = gincl[c] - (c ? gincl[c - 1] : 0u);
+	const u32 gbase = gincl[c] - ngrp;
+	const u32 nq = (ngrp + GCHUNK - 1) / GCHUNK;
+	const u32 local = it - (iincl[c] - nb * nq);
+	const u32 j = local / nq, q = local % nq;
+	const u32 first = 64u * j, g0 = q * GCHUNK;
+	CullItem d;
+	d.ref_base = offset[c] + first;
+	d.cnt = (sp - first) < 64u ? (sp - first) : 64u;
+	d.gfirst = gbase + g0;
+	d.gcount = ((g0 + GCHUNK) < ngrp ? (g0 + GCHUNK) : ngrp) - g0;
+	return d;
+}
+
+// The items as a table (the first CULL_TABLE of them; the bench frame has 27 k): the kernel reads an item with one
+// scalar load instead of a search and four dependent loads at the head of every item
 #define CULL_TABLE (1u << 20)
-__global__ __launch_bounds__(WL_THREADS) void k_cull_items(const u32 *__restrict__ iincl, u32 C,
-							    u32 *__restrict__ item_cell)
+__global__ __launch_bounds__(WL_THREADS) void k_cull_items(const u32 *__restrict__ iincl, const u32 *__restrict__ gincl,
+							    const u32 *__restrict__ span, const u32 *__restrict__ offset, u32 C,
+							    CullItem *__restrict__ items)
 {
 	const u32 it = blockIdx.x * WL_THREADS + threadIdx.x;
 	if (it < CULL_TABLE && it < iincl[C - 1])
-		item_cell[it] = d_find_cell(iincl, C, it);
+		items[it] = d_cull_item(iincl, gincl, span, offset, C, it);
 }
 
-// CULL pass.  item -> (cell, batch of 64 triangles, chunk of GCHUNK beams).  Same test as d_cull
-// with the box as centre +- half width: f(d) = n.d ranges over n.c -+ sum_k |n_k| r_k.
+// CULL pass, lane = triangle.  Same test as d_cull with the box as centre +- half width: f(d) = n.d ranges over
+// n.c -+ sum_k |n_k| r_k.  A wave takes its items in a fixed stride, so it knows the ones to come: an item's
+// descriptor is requested three items ahead, the ids of its triangles two, their records one -- the head of an item
+// was a chain of five dependent loads (25 k cycles, half of the kernel, for 15 beam iterations on average:
+// per-wave cycle stamps).
 template <bool REC>
 __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__restrict__ iincl, const u32 *__restrict__ gincl,
 						    u32 C, const u32 *__restrict__ span, const u32 *__restrict__ offset,
@@ -955,36 +1033,73 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 						    const float *__restrict__ verts, const int *__restrict__ tris,
 						    const GBox *__restrict__ boxes, u32 *__restrict__ pair_count, u32 pair_cap,
 						    u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri, u32 sbits,
-						    const u32 *__restrict__ item_cell)
+						    const CullItem *__restrict__ table)
 {
 #pragma clang fp contract(fast) // cull arithmetic only (conservative by margin); no exact test in this kernel
 	// candidate pairs are staged in LDS and flushed PAIR_BUF at a time: one atomic on the shared
 	// output cursor per ~450 pairs instead of one per beam iteration
 	__shared__ u32 buf_beam[PAIR_BUF], buf_tri[PAIR_BUF];
 	u32 nbuf = 0; // wave-uniform
+	{ // this wave's segment of the staging arrays (pair_cap = capacity of ONE segment)
+		const u32 seg = blockIdx.x % PAIR_SEGS;
+		pair_count += seg * PAIR_SEG_STRIDE;
+		pair_beam += (size_t)seg * pair_cap;
+		pair_tri += (size_t)seg * pair_cap;
+	}
 	const u32 total = iincl[C - 1];
 	const int lane = threadIdx.x;
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
-	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
-		const u32 c = it < CULL_TABLE ? item_cell[it] : d_find_cell_wave(iincl, C, it, lane);
-		const u32 sp = span[c];
-		const u32 nb = (sp + 63u) / 64u;
-		const u32 ngrp = gincl[c] - (c ? gincl[c - 1] : 0u);
-		const u32 gbase = gincl[c] - ngrp;
-		const u32 nq = (ngrp + GCHUNK - 1) / GCHUNK;
-		const u32 local = it - (iincl[c] - nb * nq);
-		const u32 j = local / nq, q = local % nq;
-		const u32 first = 64u * j;
-		const u32 cnt = (sp - first) < 64u ? (sp - first) : 64u;
-		const bool have = (u32)lane < cnt;
-		u32 face = 0;
-		float nA[3] = { 0, 0, 0 }, nB[3] = { 0, 0, 0 }, nD[3] = { 0, 0, 0 }, nC[3] = { 0, 0, 0 };
-		float mA = 0.0f, mB = 0.0f, mD = 0.0f;
-		u32 code = 0;
-		if (have) {
-			face = value_list[offset[c] + first + lane];
-			float t9[9];
+	const u32 stride = gridDim.x;
+	u32 it = d_xcd_block();
+	// An item costs between 1 and GCHUNK beam iterations and the cost changes slowly along the list (cell by
+	// cell), so neighbouring waves -- the eight of a SIMD -- would all hold cheap or all hold expensive items,
+	// and the SIMDs with the expensive ones set the kernel's time (slowest wave 1.85 x the mean).  The waves'
+	// first items are therefore dealt out through a multiplicative permutation of the wave index.
+	if ((stride & (stride - 1u)) == 0u)
+		it = (it * 40503u) & (stride - 1u);
+	if (it >= total)
+		return;
+	// (items past the end read as empty; their loads go to the first id and its record)
+	auto item_at = [&](u32 i) -> CullItem {
+		CullItem d = { 0u, 0u, 0u, 0u };
+		if (i < total)
+			d = i < CULL_TABLE ? table[i] : d_cull_item(iincl, gincl, span, offset, C, i);
+		return d;
+	};
+	auto id_of = [&](const CullItem &d) -> u32 {
+		const u32 l = (u32)lane < d.cnt ? (u32)lane : (d.cnt ? d.cnt - 1u : 0u);
+		return value_list[d.ref_base + l];
+	};
+	CullItem d_cur = item_at(it), d_1 = item_at(it + stride), d_2 = item_at(it + 2u * stride);
+	u32 id_cur = id_of(d_cur), id_1 = id_of(d_1);
+	float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+	float rcx = 0.f;
+	if (REC) {
+		ra = rec[id_cur * 3u + 0u];
+		rb = rec[id_cur * 3u + 1u];
+		rcx = reinterpret_cast<const float *>(rec)[id_cur * 12u + 8u];
+	}
+	for (;;) {
+		const bool have = (u32)lane < d_cur.cnt;
+		const u32 face = id_cur;
+		float t9[9];
+		if (REC) {
+			t9[0] = lx - ra.x, t9[1] = ly - ra.y, t9[2] = lz - ra.z;
+			t9[3] = ra.w, t9[4] = rb.x, t9[5] = rb.y, t9[6] = rb.z, t9[7] = rb.w, t9[8] = rcx;
+			// the loads of the items to come
+			ra = rec[id_1 * 3u + 0u];
+			rb = rec[id_1 * 3u + 1u];
+			rcx = reinterpret_cast<const float *>(rec)[id_1 * 12u + 8u];
+		} else {
 			d_load_triangle<REC>(rec, verts, tris, face, lx, ly, lz, t9);
+		}
+		id_cur = id_1;
+		id_1 = id_of(d_2);
+		const CullItem d_3 = item_at(it + 3u * stride);
+		float nA[3], nB[3], nD[3], nC[3];
+		float mA, mB, mD;
+		u32 code;
+		{
 			const float *tv = &t9[0], *e1 = &t9[3], *e2 = &t9[6];
 			D_CROSS(nA, e2, tv);
 			D_CROSS(nB, tv, e1);
@@ -1006,13 +1121,12 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 			code = (255u - (u32)lc) >> (8u - sbits);
 		}
 		const float mC = mA + mB + mD;
-		const u32 g0 = q * GCHUNK;
-		const u32 g1 = (g0 + GCHUNK) < ngrp ? (g0 + GCHUNK) : ngrp;
-		GBox nxt = boxes[gbase + g0]; // wave-uniform address: scalar loads
+		const u32 g0 = d_cur.gfirst, g1 = d_cur.gfirst + d_cur.gcount;
+		GBox nxt = boxes[g0]; // wave-uniform address: scalar loads
 		for (u32 g = g0; g < g1; g++) {
 			const GBox bx = nxt;
 			// the next beam's box is requested before this one is used: its latency hides behind the test
-			nxt = boxes[gbase + ((g + 1 < g1) ? g + 1 : g)];
+			nxt = boxes[(g + 1 < g1) ? g + 1 : g];
 			bool keep = false;
 			if (have) {
 				const float Dm = nD[0] * bx.cx + nD[1] * bx.cy + nD[2] * bx.cz;
@@ -1036,7 +1150,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 			if (mask != 0ull) {
 				if (keep) {
 					const u32 pos = nbuf + d_rank_in_mask(mask);
-					buf_beam[pos] = ((gbase + g) << sbits) | code;
+					buf_beam[pos] = (g << sbits) | code;
 					buf_tri[pos] = face;
 				}
 				nbuf += (u32)__popcll(mask);
@@ -1046,6 +1160,12 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 				}
 			}
 		}
+		it += stride;
+		if (it >= total)
+			break;
+		d_cur = d_1;
+		d_1 = d_2;
+		d_2 = d_3;
 	}
 	if (nbuf)
 		d_flush_pairs(buf_beam, buf_tri, nbuf, lane, pair_count, pair_cap, pair_beam, pair_tri);
@@ -1401,10 +1521,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg + maxg * (beam / 64u)),
 			   (float4 *)ctx->sray.p);
 	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * 4)))
+	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * sizeof(CullItem))))
 		return rc;
-	hipLaunchKernelGGL(k_cull_items, dim3(CULL_TABLE / WL_THREADS), dim3(WL_THREADS), 0, st, (const u32 *)iincl, C,
-			   (u32 *)ctx->citem.p);
+	hipLaunchKernelGGL(k_cull_items, dim3(CULL_TABLE / WL_THREADS), dim3(WL_THREADS), 0, st, (const u32 *)iincl,
+			   (const u32 *)gincl, d_span, d_offset, C, (CullItem *)ctx->citem.p);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	u32 sbits = ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] >= 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] : 4u;
@@ -1445,19 +1565,25 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			cap = ctx->tval[1].cap / 4;
 		if (cap > 0xFFFFFFF0u)
 			cap = 0xFFFFFFF0u;
-		if (attempt)
-			UGRT_HIP(hipMemsetAsync(pcount, 0, 4, st));
+		if ((rc = ugrt_buf_reserve(ctx, ctx->pseg, (size_t)PAIR_SEGS * PAIR_SEG_STRIDE * 4)))
+			return rc;
+		u32 *segcnt = (u32 *)ctx->pseg.p;
+		const u32 segcap = (u32)(cap / PAIR_SEGS);
+		UGRT_HIP(hipMemsetAsync(segcnt, 0, (size_t)PAIR_SEGS * PAIR_SEG_STRIDE * 4, st));
 		ugrt_prof_begin(ctx, UGRT_ST_SHADOW_CULL);
 		if (use_rec)
 			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(launch_blocks_for(0xFFFFFFFFu, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
-					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits,
-					   (const u32 *)ctx->citem.p);
+					   (const GBox *)boxes, segcnt, segcap, (u32 *)ctx->tkey[1].p, (u32 *)ctx->tval[1].p, sbits,
+					   (const CullItem *)ctx->citem.p);
 		else
 			hipLaunchKernelGGL(k_shadow_cull<false>, dim3(launch_blocks_for(0xFFFFFFFFu, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
-					   (const GBox *)boxes, pcount, (u32)cap, (u32 *)ctx->tkey[0].p, (u32 *)ctx->tval[0].p, sbits,
-					   (const u32 *)ctx->citem.p);
+					   (const GBox *)boxes, segcnt, segcap, (u32 *)ctx->tkey[1].p, (u32 *)ctx->tval[1].p, sbits,
+					   (const CullItem *)ctx->citem.p);
+		hipLaunchKernelGGL(k_pair_compact, dim3(PAIR_SEGS * 16u), dim3(256), 0, st, (const u32 *)segcnt, segcap,
+				   (const u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[1].p, (u32 *)ctx->tkey[0].p,
+				   (u32 *)ctx->tval[0].p, pcount);
 		ugrt_prof_end(ctx, UGRT_ST_SHADOW_CULL);
 		UGRT_HIP(hipGetLastError());
 		if (async) {

@@ -184,7 +184,7 @@ def main():
                     help="one stream: every stage after the other (default: light/uniform grid builds and the bounce "
                          "on a second stream beside the camera and shadow passes)")
     ap.add_argument("--repeats", type=int, default=4, help="extra untimed repetitions of the K steps (spread of the figure)")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
+    ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent frames in flight: F renderers (own contexts, buffers and streams) take the steps in "
                          "turn, so the GPU works on the tail of one frame and the head of the next (1 = a frame is "
                          "finished before the next one starts; that figure is reported too, as latency)")

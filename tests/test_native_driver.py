@@ -83,7 +83,7 @@ def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect
 @pytest.mark.parametrize("extra", [[], ["--shard-builds"], ["--config3"]])
 def test_bench_two_ranks_on_one_gpu_gather_the_right_image(extra):
     """The N > 1 path of bench.py end to end with the real kernels: two ranks (both on this one GPU, gloo with host
-    staging: a rehearsal, not RCCL) render their bands with two frames in flight and builds that never wait, rank 0
+    staging: a rehearsal, not RCCL) render their bands with several frames in flight and builds that never wait, rank 0
     gathers them, and the gathered image equals the same frame rendered whole by one context."""
     import json
     import sys

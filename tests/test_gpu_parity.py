@@ -1066,3 +1066,39 @@ def test_async_builds_equal_the_waiting_form(ugrt, O, torch):
     r4.display(setup_for(ugrt, big, "ref"), shadows=True, reflect=True)
     ctx3.synchronize()
     np.testing.assert_array_equal(r3.image.cpu().numpy(), r4.image.cpu().numpy())
+
+
+def test_async_build_meets_a_wide_triangle_it_was_not_built_for(ugrt, O, torch):
+    """A grid whose last build had no wide triangle (one that covers every cell) is built asynchronously without
+    the merge stage.  When the geometry then brings one (here: a sheet around the whole scene, which the uniform
+    grid and the light grid bin to every cell), the build must report it instead of losing it: UGRT_EOVERFLOW at
+    the synchronisation, a repaired frame afterwards, equal to a context that never built asynchronously."""
+    s0 = scene(ugrt, "crash")
+    W, H, lg, ud = 256, 144, (64, 64), (32, 32, 16)
+    setup = setup_for(ugrt, s0, "ref")
+    verts = np.asarray(s0["verts"], np.float32).reshape(-1, 3)
+    lo, hi = verts.min(0), verts.max(0)
+    d = hi - lo
+    sheet = np.array([lo - 0.01 * d, [hi[0] + 0.01 * d[0], hi[1] + 0.01 * d[1], lo[2] - 0.01 * d[2]],
+                      [lo[0] - 0.01 * d[0], hi[1] + 0.01 * d[1], hi[2] + 0.01 * d[2]]], np.float32)
+    v2 = np.concatenate([verts, sheet])
+    f2 = np.concatenate([np.asarray(s0["faces"], np.int32), np.array([[len(verts), len(verts) + 1, len(verts) + 2]], np.int32)])
+    s1 = dict(s0)
+    s1.update(verts=v2, faces=f2, matidx=np.concatenate([np.asarray(s0["matidx"], np.int32), np.zeros(1, np.int32)]))
+    ctx, r = make(ugrt, s0, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    ctx.set_option("async_build", 1)
+    for _ in range(3):
+        r.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    r1 = ugrt.Renderer(ctx, s1["verts"], s1["faces"], s1["matidx"], s1["mat_list"], s1["reflect"])
+    r1.display(setup, shadows=True, reflect=True)
+    with pytest.raises(ugrt.UgrtError, match="asynchronous"):
+        ctx.synchronize()
+    for _ in range(3):  # waits once and sizes exactly, then runs asynchronously again (now with the merge stage)
+        r1.display(setup, shadows=True, reflect=True)
+    ctx.synchronize()
+    want = O.frame(s1, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud, all_chunks=True)
+    for n, k in (("intersect_id", "mat_ids"), ("is_shadowed", "is_shadowed"), ("hit_id", "hit_id"), ("image", "image")):
+        np.testing.assert_array_equal(getattr(r1, n).cpu().numpy(), want[k], err_msg=n)
+    gi = ctx.grid_info(ugrt.GRID_UNIFORM)
+    assert gi.total_refs > gi.num_cells  # the sheet is in every cell of the uniform grid

@@ -625,6 +625,13 @@ __global__ void k_build_check(const u32 *__restrict__ scan_last, u32 capRn, u32 
 	rw[1] = W;
 }
 
+// the tail of an asynchronous build's report when no merge kernel runs (see k_merge_wide)
+__global__ void k_report_tail(u32 *__restrict__ report_tail, const u32 *__restrict__ used, const u32 *__restrict__ status)
+{
+	report_tail[0] = *used;
+	report_tail[1] = *status;
+}
+
 static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, int ylo, int yhi)
 {
 	hipStream_t st = ctx->stream;
@@ -641,7 +648,12 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	// capacities: the last known need of this grid + a quarter; the wide list goes through the rank kernel
 	const unsigned long long active = (unsigned long long)(C / ((u32)ny * (u32)nz)) * (u32)(yhi - ylo + 1) * (u32)nz;
 	const u32 estRn = G.est_rn, estW = G.est_w;
-	u32 capRn = estRn + estRn / 4u + 65536u, capW = estW + estW / 4u + 16u;
+	// A grid that had no wide triangle in its last build (the light grid and the uniform grid of the bench scene) is
+	// built for none: the sorted references are the final lists, so the rank kernel and the two merge kernels (for
+	// such a grid: a copy of every reference) do not run.  A wide triangle that does turn up exceeds the capacity
+	// like any other count: the build is emptied and flagged, and the next one expects it.
+	const bool no_wide = estW == 0u;
+	u32 capRn = estRn + estRn / 4u + 65536u, capW = no_wide ? 0u : estW + estW / 4u + 16u;
 	if (capW > 4096u)
 		capW = 4096u;
 	unsigned long long capR = (unsigned long long)capRn + active * capW;
@@ -693,8 +705,9 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	rc = ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, launchRn, bits_for(C), rw);
 	if (rc)
 		return rc;
-	hipLaunchKernelGGL(k_wide_rank, dim3((capW + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-			   (const u32 *)wl, 0u, wsorted, (const u32 *)rw);
+	if (!no_wide)
+		hipLaunchKernelGGL(k_wide_rank, dim3((capW + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
+				   (const u32 *)wl, 0u, wsorted, (const u32 *)rw);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
@@ -707,18 +720,24 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	UGRT_HIP(hipGetLastError());
 	if ((rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C)))
 		return rc;
-	// the merged lists always go to key[0]/val[0] (without wide triangles the narrow merge is a copy)
-	hipLaunchKernelGGL(k_merge_narrow, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, (const u32 *)v1, 0u,
-			   (const u32 *)cstart, (const u32 *)G.offset.p, (const u32 *)wsorted, wb, k0, v0);
-	u32 blocks = C < 256u * 32u ? C : 256u * 32u;
-	hipLaunchKernelGGL(k_merge_wide, dim3(blocks), dim3(64), 0, st, (const u32 *)v1, (const u32 *)cstart,
-			   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0, report + 2,
-			   (const u32 *)used, (const u32 *)status);
+	if (no_wide) {
+		hipLaunchKernelGGL(k_report_tail, dim3(1), dim3(1), 0, st, report + 2, (const u32 *)used, (const u32 *)status);
+		G.keys = k1;
+		G.vals = v1;
+	} else {
+		// the merged lists go to key[0]/val[0]
+		hipLaunchKernelGGL(k_merge_narrow, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, (const u32 *)v1, 0u,
+				   (const u32 *)cstart, (const u32 *)G.offset.p, (const u32 *)wsorted, wb, k0, v0);
+		u32 blocks = C < 256u * 32u ? C : 256u * 32u;
+		hipLaunchKernelGGL(k_merge_wide, dim3(blocks), dim3(64), 0, st, (const u32 *)v1, (const u32 *)cstart,
+				   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0, report + 2,
+				   (const u32 *)used, (const u32 *)status);
+		G.keys = k0;
+		G.vals = v0;
+	}
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
-	G.keys = k0;
-	G.vals = v0;
-	G.R = (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
+	G.R = no_wide ? capRn : (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
 	G.r_exact = false;
 	G.active_cells = active;
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REPORT + 4 * gi, report, 16, hipMemcpyDeviceToHost, st));

@@ -25,6 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DDA_WAVES_THROUGHPUT, DDA_WAVES_ONE_FRAME = 3072, 1024
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -276,6 +277,11 @@ def main():
                                    helper_thread=args.waiting_builds)
             if stream is not None:
                 rr._stream = stream
+            # the bounce's persistent waves: with several frames in flight every ray group gets a wave of its own (the
+            # chip holds 3072 of them: 1.37 -> 1.33 ms); a renderer on its own caps them at 1024 so that a sort pass of
+            # its main stream finds room (its default, which the one-frame latency below is measured with)
+            if rr.aux is not None and args.frames_in_flight > 1:
+                rr.aux.set_option("dda_blocks", DDA_WAVES_THROUGHPUT)
             for kv in opts:
                 k, v = kv.split("=")
                 for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
@@ -433,6 +439,9 @@ def main():
     # latency: the same K steps with ONE frame in flight (every frame is finished before the next one is started)
     latency_ms = None
     if len(renderers) > 1:
+        user_waves = [kv for kv in opts if kv.startswith("dda_blocks=")]
+        if renderers[0].aux is not None and not user_waves:
+            renderers[0].aux.set_option("dda_blocks", DDA_WAVES_ONE_FRAME)
         torch.cuda.synchronize()
         r0 = time.perf_counter()
         for _ in range(args.steps):
@@ -442,6 +451,8 @@ def main():
         renderers[0].synchronize()
         torch.cuda.synchronize()
         latency_ms = (time.perf_counter() - r0) / args.steps * 1e3
+        if renderers[0].aux is not None and not user_waves:
+            renderers[0].aux.set_option("dda_blocks", DDA_WAVES_THROUGHPUT)
     # untimed pass: the full stage table (with two streams the stages overlap: their sum exceeds the frame)
     for c in profiled:
         c.prof_enable(True)
@@ -600,6 +611,8 @@ def main():
             "tile": 8, "light_grid": list(lg), "uniform_grid": list(udims),
             "streams": (1 if (args.no_overlap or args.shard_builds) else 2) * len(renderers),
             "frames_in_flight": len(renderers),
+            "bounce_waves": {"frames_in_flight": DDA_WAVES_THROUGHPUT if len(renderers) > 1 else DDA_WAVES_ONE_FRAME,
+                             "one_frame_in_flight": DDA_WAVES_ONE_FRAME},
             "host_waits_inside_a_frame": bool(args.waiting_builds),
             "grid_builds": "light + uniform grid in %d shards of the triangle list, all-gathered and merged" % world
                            if args.shard_builds else "replicated per rank",

@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DDA_WAVES_THROUGHPUT, DDA_WAVES_ONE_FRAME = 3072, 1024
+SHADOW_WAVES_THROUGHPUT = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -280,8 +281,11 @@ def main():
             # the bounce's persistent waves: with several frames in flight every ray group gets a wave of its own (the
             # chip holds 3072 of them: 1.37 -> 1.33 ms); a renderer on its own caps them at 1024 so that a sort pass of
             # its main stream finds room (its default, which the one-frame latency below is measured with)
+            # The two shadow kernels the other way round: alone they are fastest on 8192 waves (their default), beside
+            # three other frames on 4096 (1.35 -> 1.31 ms): the chip is shared.
             if rr.aux is not None and args.frames_in_flight > 1:
                 rr.aux.set_option("dda_blocks", DDA_WAVES_THROUGHPUT)
+                rr.ctx.set_option("shadow_waves", SHADOW_WAVES_THROUGHPUT)
             for kv in opts:
                 k, v = kv.split("=")
                 for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
@@ -407,6 +411,12 @@ def main():
                 out[k] = (a[0] + v[0], a[1] + v[1])
         return out
 
+    # (the counting pass above ran other work and left the chip idle while the host summed up: a few more untimed
+    # frames bring the pipeline of frames in flight back to its steady state before the clock starts)
+    for _ in range(2 * len(renderers)):
+        step()
+        warm += 1
+    gather.finish()
     for c in profiled:
         c.prof_enable(True, stages=tracers)
         c.prof_reset()
@@ -439,9 +449,10 @@ def main():
     # latency: the same K steps with ONE frame in flight (every frame is finished before the next one is started)
     latency_ms = None
     if len(renderers) > 1:
-        user_waves = [kv for kv in opts if kv.startswith("dda_blocks=")]
+        user_waves = [kv for kv in opts if kv.startswith("dda_blocks=") or kv.startswith("shadow_waves=")]
         if renderers[0].aux is not None and not user_waves:
             renderers[0].aux.set_option("dda_blocks", DDA_WAVES_ONE_FRAME)
+            renderers[0].ctx.set_option("shadow_waves", -1)  # the default
         torch.cuda.synchronize()
         r0 = time.perf_counter()
         for _ in range(args.steps):
@@ -453,6 +464,7 @@ def main():
         latency_ms = (time.perf_counter() - r0) / args.steps * 1e3
         if renderers[0].aux is not None and not user_waves:
             renderers[0].aux.set_option("dda_blocks", DDA_WAVES_THROUGHPUT)
+            renderers[0].ctx.set_option("shadow_waves", SHADOW_WAVES_THROUGHPUT)
     # untimed pass: the full stage table (with two streams the stages overlap: their sum exceeds the frame)
     for c in profiled:
         c.prof_enable(True)
@@ -613,6 +625,8 @@ def main():
             "frames_in_flight": len(renderers),
             "bounce_waves": {"frames_in_flight": DDA_WAVES_THROUGHPUT if len(renderers) > 1 else DDA_WAVES_ONE_FRAME,
                              "one_frame_in_flight": DDA_WAVES_ONE_FRAME},
+            "shadow_waves": {"frames_in_flight": SHADOW_WAVES_THROUGHPUT if len(renderers) > 1 else 8192,
+                             "one_frame_in_flight": 8192},
             "host_waits_inside_a_frame": bool(args.waiting_builds),
             "grid_builds": "light + uniform grid in %d shards of the triangle list, all-gathered and merged" % world
                            if args.shard_builds else "replicated per rank",

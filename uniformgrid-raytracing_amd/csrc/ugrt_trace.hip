@@ -1502,7 +1502,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// rays per beam: the cull pass costs (triangles of the cell) x (beams of the cell); the exact pass
 	// re-culls the beam's candidates against each 64-ray sub-group, so its cost barely depends on the
 	// beam size.  ~1000 rays per beam is the measured optimum on the 1 M-triangle scene (tools/beam_sweep.py)
-	u32 beam = ctx->opt[UGRT_OPT_SHADOW_BEAM] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_BEAM] : 1024u;
+	u32 beam = ctx->opt[UGRT_OPT_SHADOW_BEAM] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_BEAM] : 2048u;
 	beam = beam < 64u ? 64u : (beam > 8192u ? 8192u : (beam + 63u) / 64u * 64u);
 	// candidates per exact-pass work item: a 64-ray sub-group stops at the first batch after which all its
 	// rays are flagged, so long items cost little where everything is in shadow; short items bound the

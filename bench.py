@@ -324,6 +324,7 @@ def main():
             for rr in rs:
                 rr.close()
             del rs
+            gc.collect()  # the round's contexts and their device buffers go now, not at some later collection
             times = [None] * world
             dist.all_gather_object(times, float(mine))
             balance_log.append({"bounds": list(bounds), "band_ms": [round(t, 4) for t in times]})

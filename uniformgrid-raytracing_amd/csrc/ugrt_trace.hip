@@ -860,18 +860,22 @@ __device__ __forceinline__ ShadowRay d_shadow_ray(const CamBlock &cam, const flo
 	return r;
 }
 
-// one wave per beam (`beam` = 64..256 re-grouped rays of one light cell): direction box of its rays
-__global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__restrict__ gincl, u32 C,
+// one workgroup of four waves per beam (`beam` re-grouped rays of one light cell): direction box of its rays.  The
+// waves take the beam's 64-ray runs in turn and keep per-lane minima and maxima; the lanes are folded once at the end
+// (one wave and a wave reduction per run took 49 us beside other frames once the beams were 2048 rays long).
+#define BOX_WAVES 4
+__global__ __launch_bounds__(64 * BOX_WAVES) void k_shadow_boxes(CamBlock cam, const u32 *__restrict__ gincl, u32 C,
 						     const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
 						     const u32 *__restrict__ ray_pixels, const float *__restrict__ t_value_list,
 						     const float *__restrict__ ray_direction_list,
 						     const float *__restrict__ cmPt, GBox *__restrict__ boxes, u32 beam,
 						     u32 *__restrict__ zero, u32 nzero, float4 *__restrict__ sray)
 {
-	for (u32 z = blockIdx.x * 64u + threadIdx.x; z < nzero; z += gridDim.x * 64u)
+	__shared__ float s_box[BOX_WAVES][6];
+	for (u32 z = blockIdx.x * (64u * BOX_WAVES) + threadIdx.x; z < nzero; z += gridDim.x * (64u * BOX_WAVES))
 		zero[z] = 0; // candidate run starts/ends per beam, written after the pair sort
 	const u32 total = gincl[C - 1];
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
 	const float inf = __builtin_huge_valf();
 	for (u32 g = blockIdx.x; g < total; g += gridDim.x) {
@@ -882,27 +886,39 @@ __global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__
 		const u32 left = rend[c] - start;
 		const u32 cnt = left < beam ? left : beam;
 		float lo[3] = { inf, inf, inf }, hi[3] = { -inf, -inf, -inf };
-		for (u32 b = 0; b < cnt; b += 64) {
-			const bool have = b + (u32)lane < cnt;
-			float rd[3] = { 0.0f, 0.0f, 0.0f };
-			if (have) {
+		for (u32 b = 64u * (u32)wave; b < cnt; b += 64u * BOX_WAVES) {
+			if (b + (u32)lane < cnt) {
 				ShadowRay r =
 					d_shadow_ray(cam, t_value_list, ray_direction_list, cm, (int)ray_pixels[start + b + lane]);
-				rd[0] = r.rd[0];
-				rd[1] = r.rd[1];
-				rd[2] = r.rd[2];
 				// the rebuilt ray, in beam order: the exact pass reads 64 of them as one 1-KB run instead of
 				// gathering t and direction per pixel for every (segment, sub-group) item again
 				sray[start + b + lane] = make_float4(r.rd[0], r.rd[1], r.rd[2], r.distance_b);
-			}
-			const DirBox bx = d_dir_box(rd, have);
 #pragma unroll
-			for (int k = 0; k < 3; k++) {
-				lo[k] = fminf(lo[k], bx.lo[k]);
-				hi[k] = fmaxf(hi[k], bx.hi[k]);
+				for (int k = 0; k < 3; k++) {
+					lo[k] = fminf(lo[k], r.rd[k]);
+					hi[k] = fmaxf(hi[k], r.rd[k]);
+				}
 			}
 		}
-		if (lane == 0) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			const float l = d_wave_fmin(lo[k]), h = d_wave_fmax(hi[k]);
+			if (lane == 0) {
+				s_box[wave][k] = l;
+				s_box[wave][3 + k] = h;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				lo[k] = s_box[0][k];
+				hi[k] = s_box[0][3 + k];
+				for (int w = 1; w < BOX_WAVES; w++) {
+					lo[k] = fminf(lo[k], s_box[w][k]);
+					hi[k] = fmaxf(hi[k], s_box[w][3 + k]);
+				}
+			}
 			GBox o;
 			o.cx = 0.5f * (lo[0] + hi[0]);
 			o.cy = 0.5f * (lo[1] + hi[1]);
@@ -915,6 +931,7 @@ __global__ __launch_bounds__(64) void k_shadow_boxes(CamBlock cam, const u32 *__
 			o.ray_count = cnt;
 			boxes[g] = o;
 		}
+		__syncthreads();
 	}
 }
 
@@ -1516,7 +1533,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	if ((rc = ugrt_prim_inclusive_scan(ctx, icnt, iincl, C)))
 		return rc;
-	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64), 0, st, ctx->cam,
+	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64 * BOX_WAVES), 0, st, ctx->cam,
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
 			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg + maxg * (beam / 64u)),
 			   (float4 *)ctx->sray.p);

@@ -11,8 +11,11 @@ frame (as the reference does), scene and buffers are resident in HBM before the 
   python bench.py --gpus N --steps K --warmup W
 N = 1: BASELINE configs[2] (1M-triangle "crashing" stand-in, 1920x1080).  N > 1: one process
 per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE), the image is cut into bands of tile rows
-and grows with N at fixed 16:9 aspect (weak scaling; N = 4 is configs[3]'s 3840x2160).
-Prints ONE JSON line on rank 0.
+and grows with N at fixed 16:9 aspect (weak scaling; N = 4 is configs[3]'s 3840x2160); the bands
+are timed and their boundaries moved before the measurement (--balance-rounds).
+Consecutive frames go to --frames-in-flight renderers with their own contexts and streams (every
+frame is complete: all grids rebuilt); the time of a frame that has the GPU to itself is reported
+beside the rate as ms_per_step_one_frame_in_flight.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import gc

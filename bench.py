@@ -217,6 +217,11 @@ def main():
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
 
+    # The frames in flight use 2 streams each; the HIP runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues
+    # (default 4), so with four frames two streams share a queue: kernels of different streams in one queue still
+    # overlap, but the chip works on fewer of them at once.  That is the fast arrangement here (1.28 ms; 3 queues
+    # 1.46, 5-8 queues 1.55-1.60, i.e. every stream with a queue of its own is SLOWER), so it is pinned, not assumed.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
     import numpy as np
     import torch
 

@@ -173,6 +173,31 @@ def cpu_baseline(ugrt, s, setup, W, H, lg, udims, seconds):
     return out
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` without an external launcher: start N ranks (one process per GPU) through
+    torch.distributed.run and relay rank 0's JSON line.  This parent never touches the GPU and does not replace
+    itself: the ranks are child processes, and the exit code is theirs."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:  # a free rendezvous port on the loopback interface
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] --gpus %d without WORLD_SIZE: starting %d ranks: %s" % (n, n, " ".join(cmd)))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in p.stdout:  # the ranks' stderr is inherited; stdout carries rank 0's line (and nothing else of ours)
+        if ln.startswith('{"metric"'):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,9 +229,11 @@ def main():
     ap.add_argument("--no-static-geometry", action="store_true",
                     help="rebuild the per-triangle records in every grid build, as a caller that rewrites the vertex array "
                          "behind the library's back must (default: UGRT_FLAG_STATIC_GEOMETRY, the renderer is the only writer)")
-    ap.add_argument("--verify", action="store_true",
-                    help="after the timed region rank 0 renders the whole frame on one context and compares it with the "
-                         "gathered image of the last step (byte for byte)")
+    ap.add_argument("--no-verify", dest="verify", action="store_false",
+                    help="skip the check behind the timed region (default: on).  N = 1: the buffers every renderer in flight "
+                         "holds from its last frame (image, shadow flags, ids, t, normals, directions, bounce hits) are "
+                         "compared bit for bit with ONE sequential context whose builds wait (one stream, one frame, no "
+                         "estimates); N > 1: rank 0 renders the whole frame that way and compares the gathered image")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE",
                     help="launch-shape option for every context (ugrt_ctx_set_option), e.g. dda_kernel=1")
     ap.add_argument("--uniform-grid", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
@@ -216,6 +243,8 @@ def main():
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # before anything that could initialise the GPU in this process
 
     # The frames in flight use 2 streams each; the HIP runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues
     # (default 4), so with four frames two streams share a queue: kernels of different streams in one queue still
@@ -232,8 +261,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started inside a job of %d ranks (WORLD_SIZE)" % (args.gpus, world))
     dist = None
     # Rehearsal on a ONE-GPU box (UGRT_BENCH_REHEARSE=1): every rank uses device 0 and the collectives go
     # through gloo with host staging.  It exercises the multi-rank code path, not RCCL, and is never a result.
@@ -511,9 +539,10 @@ def main():
         alone = {k: round(v[0] / nfull, 4) for k, v in sorted(actx.prof_get().items()) if v[1]}
         del ar, actx
 
-    verified = None
+    verified, verify_detail = None, None
     if args.verify:
-        # one more step, gathered synchronously, against the same frame rendered whole by one context
+        # one more step, gathered synchronously; then the same frame(s) by ONE sequential context: one stream, one frame
+        # at a time, builds that wait and size everything exactly (no estimates, no second stream)
         last = renderers[turn[0] % len(renderers)]
         step()
         gather.finish()
@@ -525,13 +554,26 @@ def main():
         if rank == 0:
             fctx = ugrt.Context(W, H, device=local, light_grid=lg, flags=flags, uniform_dims=udims)
             fr = ugrt.Renderer(fctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
-            fr.d_verts.copy_(last.d_verts)
-            fctx.geometry_changed()
-            fr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
-            fctx.synchronize()
-            torch.cuda.synchronize()
-            verified = bool(torch.equal(fr.image, last.image))
-            log("[bench] verify: gathered image %s the single-context frame" % ("==" if verified else "!="))
+
+            def same(a, b):
+                return bool(torch.equal(a.view(torch.uint8), b.view(torch.uint8)))
+
+            verify_detail = []
+            # N = 1: every renderer in flight holds the buffers of its last frame; N > 1: the gathered image
+            for rr in (renderers if world == 1 else [last]):
+                fr.d_verts.copy_(rr.d_verts)
+                fctx.geometry_changed()
+                fr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+                fctx.synchronize()
+                torch.cuda.synchronize()
+                names = ["image"]
+                if world == 1:
+                    names += ["is_shadowed", "intersect_id", "t", "normal", "dir"] + (["hit_t", "hit_id", "active"] if reflect else [])
+                bad = [k for k in names if not same(getattr(fr, k), getattr(rr, k))]
+                verify_detail.append(bad)
+            verified = all(not b for b in verify_detail)
+            log("[bench] verify: %d renderer(s) against one sequential waiting-build context: %s"
+                % (len(verify_detail), "all buffers equal" if verified else "DIFFERENT: %r" % (verify_detail,)))
             del fr, fctx
     tot = torch.tensor([elapsed, float(rays_rank)], dtype=torch.float64, device="cpu" if rehearse else ctx.device)
     if dist is not None:
@@ -577,7 +619,11 @@ def main():
                     note="achieved = algorithmic bytes of THIS kernel (SURVEY 8(d): 48 B per ray + 8 B per cell visited + "
                          "52 B per triangle tested, as the per-ray algorithm counts them) / its launch time from hipEvents "
                          "on its own stream inside the timed loop; traffic = HBM bytes per launch from rocprofv3 PMC "
-                         "passes of the same build (2*FETCH_SIZE + WRITE_SIZE, KiB units)")
+                         "passes of the same build (2*FETCH_SIZE + WRITE_SIZE, KiB units).  The factor 2 on FETCH_SIZE is the "
+                         "guide's correction for wide coalesced streaming reads; this kernel gathers (4-48 B per lane), for "
+                         "which the factor is uncalibrated: read traffic as an UPPER bound (between FETCH_SIZE + WRITE_SIZE "
+                         "and the figure given)",
+                    traffic_is_upper_bound=True)
     # whole-frame HBM figure: all kernels' PMC bytes of one frame over the frame time
     frame_hbm = None
     if tent and tent.get("frame_bytes"):
@@ -627,10 +673,11 @@ def main():
         "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU, gloo; not a result)",
         "config": {
             "workload": ("BASELINE configs[%d] stand-in: procedural '%s' scene, %d triangles, %dx%d, primary + "
-                         "shadow (1 light, all chunks traced)%s; all grids rebuilt every frame%s"
+                         "shadow (1 light, all chunks traced)%s; all three grids rebuilt every frame%s%s"
                          % (4 if args.animate else (2 if reflect else 1), s["name"], s["num_faces"], W, H,
                             " + 1 reflection bounce" if reflect else "",
-                            "; animated sub-range transformed every frame" if args.animate else "")),
+                            "; animated sub-range transformed every frame" if args.animate else "",
+                            "" if args.no_static_geometry else " (per-triangle records kept between builds: static geometry flag)")),
             "frames_per_s": round(args.steps / elapsed, 2),
             "rays_per_frame": int(rays_total),
             "tile": 8, "light_grid": list(lg), "uniform_grid": list(udims),
@@ -641,6 +688,10 @@ def main():
             "shadow_waves": {"frames_in_flight": SHADOW_WAVES_THROUGHPUT if len(renderers) > 1 else 8192,
                              "one_frame_in_flight": 8192},
             "host_waits_inside_a_frame": bool(args.waiting_builds),
+            "static_geometry": not args.no_static_geometry,  # UGRT_FLAG_STATIC_GEOMETRY: triangle records kept between builds
+            "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
+            "n_gt_1_default": "weak scaling: the image grows with N at 16:9 (N = 4 is configs[3]'s 3840x2160); "
+                              "--config3 = ONE 3840x2160 frame cut into N bands",
             "grid_builds": "light + uniform grid in %d shards of the triangle list, all-gathered and merged" % world
                            if args.shard_builds else "replicated per rank",
             "parallelism": "image bands of tile rows, 1 process per GPU, RCCL gather of RGB" if world > 1 else "1 GPU",
@@ -650,6 +701,7 @@ def main():
         "work_reduction": work_reduction,
         "cpu_baseline": cpu,
         "verified_against_single_context_frame": verified,
+        "verify_mismatches_per_renderer": verify_detail,
         "repeat_ms_per_step": [round(x, 4) for x in repeats],
         "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),

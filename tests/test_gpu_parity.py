@@ -198,6 +198,52 @@ def test_reflection_bounce(ugrt, O, torch, name, cam, W, H):
     assert want["active"].sum() > 100 and (want["hit_id"] >= 0).sum() > 100
 
 
+@pytest.mark.parametrize("name,W,H,ud", [("crash", 256, 144, (32, 32, 16)), ("crash", 320, 200, (64, 64, 32)),
+                                         ("hall", 256, 256, (16, 16, 8)), ("cornell", 128, 128, (8, 8, 8))])
+def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
+    """The three bounce kernels (0 window kernel, 1 per-ray, 2 beam kernel of round 2) at every launch shape, with
+    and without the (entry cell, octant) ray sort: hit ids equal, t bit-equal to the oracle; the counting variants
+    report the oracle's work counts (tests, cells, rays of the algorithmic-byte formula)."""
+    s = dict(scene(ugrt, name))
+    if name == "cornell":  # every material reflects: rays in all directions through a coarse grid
+        s["reflect"] = np.full(len(np.asarray(s["mat_list"]).reshape(-1, 6)), 0.5, np.float32)
+    lg = (64, 64)
+    cam = "ref" if name != "cornell" else "B"
+    setup = setup_for(ugrt, s, cam)
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud, shadows=False)
+    assert want["active"].sum() > 100
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    r.display(setup, shadows=False, reflect=True)
+    ctx.synchronize()
+    uvalue, uspan, uoffset, _ = ctx.grid_ptrs(ugrt.GRID_UNIFORM)
+    shapes = [dict(dda_kernel=0), dict(dda_kernel=0, dda_rays_per_wave=16), dict(dda_kernel=0, dda_rays_per_wave=32),
+              dict(dda_kernel=0, dda_cull_min=1), dict(dda_kernel=0, dda_cull_min=1 << 30), dict(dda_kernel=0, dda_sort=1),
+              dict(dda_kernel=0, dda_sort=1, dda_rays_per_wave=24), dict(dda_kernel=0, dda_blocks=7),
+              dict(dda_kernel=1), dict(dda_kernel=2), dict(dda_kernel=2, dda_sort=1)]
+    for opts in shapes:
+        for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_sort", "dda_blocks"):
+            ctx.set_option(k, opts.get(k, -1))
+        r.hit_t.fill_(7.0)
+        r.hit_id.fill_(7)
+        ctx.trace_dda(uvalue, uspan, uoffset, r.d_verts, r.d_faces, r.rays, r.active, r.hit_t, r.hit_id)
+        ctx.synchronize()
+        np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want["hit_id"], err_msg=str(opts))
+        assert_bits_equal(r.hit_t.cpu().numpy(), want["hit_t"], "dda t %r" % (opts,))
+    # counting variants
+    cctx, cr = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_COUNT_WORK, udims=ud)
+    cr.display(setup, shadows=False, reflect=True)
+    cctx.synchronize()
+    cv, cs, co, _ = cctx.grid_ptrs(ugrt.GRID_UNIFORM)
+    for k in (0, 1, 2):
+        cctx.set_option("dda_kernel", k)
+        cr.hit_t.fill_(7.0)
+        cctx.trace_dda(cv, cs, co, cr.d_verts, cr.d_faces, cr.rays, cr.active, cr.hit_t, cr.hit_id)
+        st = cctx.stats()
+        assert [int(st[3]), int(st[4]), int(st[5])] == want["dda_counters"], (k, st[3:6], want["dda_counters"])
+        np.testing.assert_array_equal(cr.hit_id.cpu().numpy(), want["hit_id"])
+        assert_bits_equal(cr.hit_t.cpu().numpy(), want["hit_t"], "counting kernel %d" % k)
+
+
 def test_animation(ugrt, O, torch):
     """copy_data_transform (transformation_kernel.cu:4) then a rebuilt frame."""
     s = scene(ugrt, "crash")

@@ -47,32 +47,37 @@ ms_ray = run(ctx, r)
 ref_t, ref_id = r.hit_t.clone(), r.hit_id.clone()
 print("per-ray kernel, 32 rays per wave: %.3f ms" % ms_ray, flush=True)
 res["per_ray_rpw32_ms"] = ms_ray
-ctx.set_option("dda_kernel", 0)
-for rpw in (16, 32, 64):
-    for cull_min in ((8,) if quick else (8, 1 << 30)):
-        for coop in (8,):
-            ctx.set_option("dda_rays_per_wave", rpw)
-            ctx.set_option("dda_cull_min", cull_min)
-            ctx.set_option("dda_coop", coop)
-            r.hit_t.fill_(7.0)
-            r.hit_id.fill_(7)
-            ms = run(ctx, r)
-            same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
-            print("beam rpw %2d cull_min %10d coop %2d : %.3f ms  identical=%s" % (rpw, cull_min, coop, ms, same), flush=True)
-            res["rows"].append({"rpw": rpw, "cull_min": cull_min, "coop": coop, "ms": ms, "identical": same})
+for kernel in (2, 0):  # 2 = beam kernel of round 2, 0 = window kernel
+    for sort in (0, 1):
+        for rpw in ((64,) if (quick or sort) else (16, 32, 64)):
+            for cull_min in ((8,) if (quick or kernel == 2 or sort) else (8, 4, 16, 1 << 30)):
+                ctx.set_option("dda_kernel", kernel)
+                ctx.set_option("dda_sort", sort)
+                ctx.set_option("dda_rays_per_wave", rpw)
+                ctx.set_option("dda_cull_min", cull_min)
+                r.hit_t.fill_(7.0)
+                r.hit_id.fill_(7)
+                ms = run(ctx, r)
+                same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
+                print("kernel %d sort %d rpw %2d cull_min %10d : %.3f ms  identical=%s" % (kernel, sort, rpw, cull_min, ms, same),
+                      flush=True)
+                res["rows"].append({"kernel": kernel, "sort": sort, "rpw": rpw, "cull_min": cull_min, "ms": ms,
+                                    "identical": same})
+ctx.set_option("dda_sort", 0)
 # work counters
 cctx, cr = make(ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_COUNT_WORK)
-for k in (0, 1):
+for k, sort in ((1, 0), (2, 0), (0, 0), (0, 1)):
     cctx.set_option("dda_kernel", k)
+    cctx.set_option("dda_sort", sort)
     uv, us, uo, _ = cctx.grid_ptrs(ugrt.GRID_UNIFORM)
     cctx.trace_dda(uv, us, uo, cr.d_verts, cr.d_faces, cr.rays, cr.active, cr.hit_t, cr.hit_id)
     st = cctx.stats()
-    print("kernel %d: tests %d cells %d rays %d" % (k, st[3], st[4], st[5]), flush=True)
-    res["work_kernel%d" % k] = {"tests": st[3], "cells": st[4], "rays": st[5]}
-    if k == 0:
-        d = cctx.stats_dda()
-        print("beam sharing:", d, flush=True)
-        res["beam_sharing"] = d
+    print("kernel %d sort %d: tests %d cells %d rays %d" % (k, sort, st[3], st[4], st[5]), flush=True)
+    res["work_kernel%d_sort%d" % (k, sort)] = {"tests": st[3], "cells": st[4], "rays": st[5]}
+    if k != 1:
+        d = cctx.stats_dda(kernel=k)
+        print("sharing:", d, flush=True)
+        res["sharing_kernel%d_sort%d" % (k, sort)] = d
         res["algorithmic_bytes"] = 48 * st[5] + 8 * st[4] + 52 * st[3]
 if out:
     json.dump(res, open(out, "w"), indent=1)

@@ -681,8 +681,12 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
 	u32 *rw = ctx->d_small + UGRT_DSMALL_RW + 2 * gi, *status = ctx->d_small + UGRT_DSMALL_STATUS;
 	u32 *report = ctx->d_small + UGRT_DSMALL_REPORT + 4 * gi;
-	hipLaunchKernelGGL(k_build_check, dim3(1), dim3(1), 0, st, (const u32 *)G.scan.p + (F - 1), capRn, capW, capR, active, rw,
-			   status, report);
+	// launch sizes: the estimate plus the margin (every kernel stops at the real count).  The check below is made
+	// against THIS size, not against the (larger, grow-only) buffers: fill, sort, bounds and merge run one thread per
+	// reference of the launch, so a count between the two would leave references unfilled and unsorted.
+	const u32 launchRn = estRn + estRn / 4u + 65536u < capRn ? estRn + estRn / 4u + 65536u : capRn;
+	hipLaunchKernelGGL(k_build_check, dim3(1), dim3(1), 0, st, (const u32 *)G.scan.p + (F - 1), launchRn, capW, capR, active,
+			   rw, status, report);
 	UGRT_HIP(hipGetLastError());
 	WideBox wb;
 	wb.W = 0;
@@ -691,8 +695,6 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	wb.ylo = (u32)ylo;
 	wb.yhi = (u32)yhi;
 	wb.rw = rw;
-	// launch sizes: the estimate plus the margin (every kernel stops at the real count)
-	const u32 launchRn = estRn + estRn / 4u + 65536u < capRn ? estRn + estRn / 4u + 65536u : capRn;
 	const u32 nparts = (launchRn + BUILD_THREADS - 1) / BUILD_THREADS;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
@@ -737,7 +739,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	}
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
-	G.R = no_wide ? capRn : (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
+	G.R = no_wide ? launchRn : (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
 	G.r_exact = false;
 	G.active_cells = active;
 	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REPORT + 4 * gi, report, 16, hipMemcpyDeviceToHost, st));

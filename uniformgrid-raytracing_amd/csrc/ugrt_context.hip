@@ -143,6 +143,8 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->witems);
 	buf_free(ctx->wcount);
 	buf_free(ctx->wscan);
+	buf_free(ctx->ubitmap);
+	buf_free(ctx->dsort);
 	buf_free(ctx->best);
 	buf_free(ctx->rmap[0]);
 	buf_free(ctx->rmap[1]);
@@ -187,13 +189,13 @@ static const struct {
 	const char *key;
 	int lo, hi;
 } k_opt[UGRT_OPT_COUNT] = {
-	{ "dda_rays_per_wave", 0, 64 }, { "dda_coop", 1, 1 << 30 },     { "dda_kernel", 0, 1 },
+	{ "dda_rays_per_wave", 0, 64 }, { "dda_coop", 1, 1 << 30 },     { "dda_kernel", 0, 2 },
 	{ "dda_cull_min", 1, 1 << 30 }, { "dda_blocks", 1, 1 << 20 },
 	{ "primary_seg", 64, 1 << 20 }, { "shadow_beam", 64, 8192 },
 	{ "shadow_xseg", 64, 1 << 20 }, { "shadow_sizebits", 0, 8 },    { "shadow_itemsort", 0, 1 },
 	{ "shadow_mbits", 1, 24 },      { "shadow_key64", 0, 1 },       { "sort_library", 0, 1 },
 	{ "async_build", 0, 1 },        { "primary_waves", 64, 1 << 20 },
-	{ "shadow_waves", 64, 1 << 20 },
+	{ "shadow_waves", 64, 1 << 20 }, { "dda_sort", 0, 1 },
 };
 
 extern "C" int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value)

@@ -22,7 +22,7 @@ struct CamBlock {
 enum {
 	UGRT_OPT_DDA_RPW = 0,      // "dda_rays_per_wave"
 	UGRT_OPT_DDA_COOP,         // "dda_coop": list length from which a lone ray's cell is tested by the whole wave
-	UGRT_OPT_DDA_KERNEL,       // "dda_kernel": 0 = beam kernel, 1 = per-ray kernel of round 1
+	UGRT_OPT_DDA_KERNEL,       // "dda_kernel": 0 = window kernel, 1 = per-ray kernel of round 1, 2 = beam kernel of round 2
 	UGRT_OPT_DDA_CULL_MIN,     // "dda_cull_min": list length from which a shared cell is culled before the exact tests
 	UGRT_OPT_DDA_BLOCKS,       // "dda_blocks": upper bound of the persistent waves of ugrt_trace_dda
 	UGRT_OPT_PRIMARY_SEG,      // "primary_seg"
@@ -36,6 +36,7 @@ enum {
 	UGRT_OPT_ASYNC_BUILD,      // "async_build": 1 = grid builds and the shadow tracer never wait for the device
 	UGRT_OPT_PRIMARY_WAVES,    // "primary_waves": single-wave workgroups of the primary tracer
 	UGRT_OPT_SHADOW_WAVES,     // "shadow_waves": the same for the two shadow kernels
+	UGRT_OPT_DDA_SORT,         // "dda_sort": 1 = the bounce's ray list is sorted by (entry cell, octant) instead of tile order
 	UGRT_OPT_COUNT
 };
 
@@ -125,6 +126,8 @@ struct ugrt_ctx {
 	int rec_faces = 0;
 	bool rec_valid = false;
 	DevBuf witems, wcount, wscan; // tracer work lists
+	DevBuf ubitmap;               // bounce: occupancy bitmap of the uniform grid's cells (1 bit per cell)
+	DevBuf dsort;                 // bounce, option dda_sort: keys + sorted keys + sorted list
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)
 	DevBuf rstart, cchunks, cbase; // ray runs per light cell (sort_rays)

@@ -12,18 +12,8 @@
 //     are tested by the group's rays (lane = ray, triangle broadcast from registers).
 //   k_trace_dda_ray (option "dda_kernel" = 1) -- round 1's kernel: every ray walks and tests alone, long
 //     lists are tested by the whole wave for one owner at a time.  Kept as the before/after reference.
-#include "ugrt_packet.h"
+#include "ugrt_dda.h"
 
-struct DGrid {
-	float lo[3], cs[3], inv[3];
-	int dims[3];
-};
-
-__device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
-{
-	int c = ugrt_floor2i((p - g.lo[k]) * g.inv[k]);
-	return d_clampi(c, 0, g.dims[k] - 1);
-}
 
 #define DDA_AHEAD 4   // cells planned (and their headers fetched) per round trip
 
@@ -309,130 +299,6 @@ __global__ __launch_bounds__(64) void k_trace_dda_ray(DGrid g, const u32 *__rest
 // ---------------------------------------------------------------------------
 // beam kernel
 // ---------------------------------------------------------------------------
-// Cull of one triangle against a BUNDLE of rays with different origins.  Moller-Trumbore's numerators do
-// not change when the origin slides along its ray (A = d.(e2 x tvec), and d.(e2 x d) = 0), so every ray of
-// the bundle is represented by the point o' = o + t_in * d where it enters the current cell: the points of
-// a bundle then lie within a fraction of a cell of each other.  With the boxes o' in oc +- orad, d in
-// dc +- dr:
-//     A = d.(e2 x (oc - v0)) + (o' - oc).(d x e2),   |second term| <= sum_k orad_k max|(d x e2)_k|
-// and likewise for B (e1 x d) and A + B - det (d x (e2 - e1)), the maxima taken over the direction box; the
-// first terms are the interval dot products of the single-origin cull (d_cull_cr).  (Bounding the second term
-// by |d| |e2| |o' - oc| instead leaves twice as many triangles for the exact tests.)  The margins cover the rounding of the exact test, whose operands are
-// tvec = o - v0 with the ray's own origin: `reach` bounds |o - oc|.  A culled triangle fails the exact
-// float test on every ray of the bundle, so results do not change by a bit.
-struct BeamBox {
-	float oc[3], orad[3], dc[3], dr[3];
-	float reach; // >= |o - oc|_inf over the bundle
-};
-
-__device__ __forceinline__ float d_uniform(float v)
-{
-	return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-}
-
-__device__ __forceinline__ BeamBox d_beam_box(const float *o, const float *d, float tin, bool in)
-{
-	BeamBox bx;
-	const float inf = __builtin_huge_valf();
-	float on2 = 0.0f, dm2 = 0.0f;
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		const float p = o[k] + tin * d[k];
-		float lo = d_wave_fmin(in ? p : inf), hi = d_wave_fmax(in ? p : -inf);
-		bx.oc[k] = 0.5f * (lo + hi);
-		// half width + the distance of the computed o' from the exact point of the ray (a few ulps of |o'|)
-		bx.orad[k] = 0.5f * (hi - lo) * 1.0001f + 7.63e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f;
-		on2 += bx.orad[k] * bx.orad[k];
-		lo = d_wave_fmin(in ? d[k] : inf);
-		hi = d_wave_fmax(in ? d[k] : -inf);
-		bx.dc[k] = 0.5f * (lo + hi);
-		bx.dr[k] = 0.5f * (hi - lo) * 1.0001f + 1e-6f;
-		const float da = fabsf(bx.dc[k]) + bx.dr[k];
-		dm2 += da * da;
-	}
-	const float tmax = d_wave_fmax(in ? tin : 0.0f);
-	const float on = __builtin_sqrtf(on2) * 1.0001f, dmax = __builtin_sqrtf(dm2) * 1.0001f;
-	bx.reach = (tmax * dmax + on) * 1.001f;
-	// uniform values: keep them in scalar registers
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		bx.oc[k] = d_uniform(bx.oc[k]);
-		bx.dc[k] = d_uniform(bx.dc[k]);
-		bx.dr[k] = d_uniform(bx.dr[k]);
-		bx.orad[k] = d_uniform(bx.orad[k]);
-	}
-	bx.reach = d_uniform(bx.reach);
-	return bx;
-}
-
-// true = no ray of the bundle can pass the exact test on triangle {v0, e1, e2}
-__device__ __forceinline__ bool d_cull_beam(const float *v0, const float *e1, const float *e2, const BeamBox &bx)
-{
-#pragma clang fp contract(fast)
-	const float tc[3] = { bx.oc[0] - v0[0], bx.oc[1] - v0[1], bx.oc[2] - v0[2] };
-	float nA[3], nB[3], nD[3], nC[3];
-	D_CROSS(nA, e2, tc);
-	D_CROSS(nB, tc, e1);
-	D_CROSS(nD, e2, e1);
-#pragma unroll
-	for (int k = 0; k < 3; k++)
-		nC[k] = nA[k] + nB[k] - nD[k];
-	const float a = fmaxf(fmaxf(fabsf(tc[0]), fabsf(tc[1])), fabsf(tc[2])) + bx.reach;
-	const float b = fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2]));
-	const float c = fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]));
-	const float K = 6.0f / 65536.0f;
-	const float mA = fmaxf(K * a * c, 1e-25f), mB = fmaxf(K * a * b, 1e-25f), mD = fmaxf(K * b * c, 1e-25f);
-	const float Dm = nD[0] * bx.dc[0] + nD[1] * bx.dc[1] + nD[2] * bx.dc[2];
-	const float Dr = fabsf(nD[0]) * bx.dr[0] + fabsf(nD[1]) * bx.dr[1] + fabsf(nD[2]) * bx.dr[2];
-	if (!(Dm + Dr < 1e15f && Dm - Dr > -1e15f))
-		return false;
-	// |w . (d x e)| over the boxes of w = o' - oc and d: sum_k orad_k * (|(dc x e)_k| + the spread of d)
-#define D_ORIGIN_TERM(E)                                                                                        \
-	(bx.orad[0] * (fabsf(bx.dc[1] * E[2] - bx.dc[2] * E[1]) + bx.dr[1] * fabsf(E[2]) + bx.dr[2] * fabsf(E[1])) + \
-	 bx.orad[1] * (fabsf(bx.dc[2] * E[0] - bx.dc[0] * E[2]) + bx.dr[2] * fabsf(E[0]) + bx.dr[0] * fabsf(E[2])) + \
-	 bx.orad[2] * (fabsf(bx.dc[0] * E[1] - bx.dc[1] * E[0]) + bx.dr[0] * fabsf(E[1]) + bx.dr[1] * fabsf(E[0])))
-	const float e21[3] = { e2[0] - e1[0], e2[1] - e1[1], e2[2] - e1[2] };
-	const float Am = nA[0] * bx.dc[0] + nA[1] * bx.dc[1] + nA[2] * bx.dc[2];
-	const float Ar = (fabsf(nA[0]) * bx.dr[0] + fabsf(nA[1]) * bx.dr[1] + fabsf(nA[2]) * bx.dr[2] + D_ORIGIN_TERM(e2)) * 1.0001f;
-	const float Bm = nB[0] * bx.dc[0] + nB[1] * bx.dc[1] + nB[2] * bx.dc[2];
-	const float Br = (fabsf(nB[0]) * bx.dr[0] + fabsf(nB[1]) * bx.dr[1] + fabsf(nB[2]) * bx.dr[2] + D_ORIGIN_TERM(e1)) * 1.0001f;
-	const float Cm = nC[0] * bx.dc[0] + nC[1] * bx.dc[1] + nC[2] * bx.dc[2];
-	const float Cr = (fabsf(nC[0]) * bx.dr[0] + fabsf(nC[1]) * bx.dr[1] + fabsf(nC[2]) * bx.dr[2] + D_ORIGIN_TERM(e21)) * 1.0001f;
-#undef D_ORIGIN_TERM
-	const float mC = mA + mB + mD;
-	if (Dm - Dr > mD) // det > 0 for every ray of the bundle
-		return (Am + Ar < -mA) || (Bm + Br < -mB) || (Cm - Cr > mC);
-	if (Dm + Dr < -mD) // det < 0
-		return (Am - Ar > mA) || (Bm - Br > mB) || (Cm + Cr < -mC);
-	return false;
-}
-
-// {v0, e1, e2} of one triangle: the 48-B record, or the gather + the reference's two edge subtractions
-template <bool REC>
-__device__ __forceinline__ void d_load_record(const float4 *__restrict__ rec, const float *__restrict__ verts,
-					      const int *__restrict__ tris, u32 face, float *r9)
-{
-	if (REC) {
-		const float4 a = rec[face * 3 + 0], b = rec[face * 3 + 1], c = rec[face * 3 + 2];
-		r9[0] = a.x;
-		r9[1] = a.y;
-		r9[2] = a.z;
-		r9[3] = a.w;
-		r9[4] = b.x;
-		r9[5] = b.y;
-		r9[6] = b.z;
-		r9[7] = b.w;
-		r9[8] = c.x;
-	} else {
-		const int f1 = 3 * tris[face * 3 + 0], f2 = 3 * tris[face * 3 + 1], f3 = 3 * tris[face * 3 + 2];
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			r9[k] = verts[f1 + k];
-			r9[3 + k] = verts[f2 + k] - r9[k];
-			r9[6 + k] = verts[f3 + k] - r9[k];
-		}
-	}
-}
 
 #define BEAM_AHEAD 8 // cells planned (and their headers fetched) per round trip of the beam kernel
 #define DDA_MAXLAG 7 // a ray may wait this many steps for the rays behind it (phase alignment, below)
@@ -815,6 +681,14 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_beam(DGrid g, const u32 *__
 }
 
 
+// ugrt_dda_walk.hip
+int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
+			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
+			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
+			 bool counting, u32 RPW, u32 CULL_MIN, int blocks);
+int ugrt_dda_sort_keys_launch(ugrt_ctx *ctx, const DGrid &g, const float *d_rays, const u32 *list, const u32 *dcount, u32 cap,
+			      u32 *keys);
+
 extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const unsigned *d_span,
 			      const unsigned *d_offset, const float *d_vertlist, const int *d_trilist,
 			      const float *d_rays, const int *d_active, float *d_hit_t, int *d_hit_id)
@@ -854,7 +728,8 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	UGRT_HIP(hipGetLastError());
 	// launch shape (ugrt_ctx_set_option; no effect on results): which kernel, rays per wave, list length from
 	// which a lone ray's cell is tested by the whole wave, list length from which a shared cell is culled first
-	const bool beam = ctx->opt[UGRT_OPT_DDA_KERNEL] != 1;
+	const int kernel = ctx->opt[UGRT_OPT_DDA_KERNEL] > 0 ? ctx->opt[UGRT_OPT_DDA_KERNEL] : 0; // 0 window, 1 per-ray, 2 beam
+	const bool beam = kernel != 1;
 	u32 DDA_RPW = ctx->opt[UGRT_OPT_DDA_RPW] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_RPW] : (beam ? 64u : 32u);
 	const u32 DDA_COOP = ctx->opt[UGRT_OPT_DDA_COOP] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_COOP] : 8u;
 	const u32 CULL_MIN = ctx->opt[UGRT_OPT_DDA_CULL_MIN] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_MIN] : 8u;
@@ -865,6 +740,49 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	int blocks = launch_blocks_for((u32)ctx->npix / DDA_RPW + 1u);
 	if (ctx->opt[UGRT_OPT_DDA_BLOCKS] > 0 && blocks > ctx->opt[UGRT_OPT_DDA_BLOCKS])
 		blocks = ctx->opt[UGRT_OPT_DDA_BLOCKS];
+	// option dda_sort (SURVEY 8f.2 as written): the list sorted by (entry cell, octant) with the frame's pair sort
+	if (ctx->opt[UGRT_OPT_DDA_SORT] == 1) {
+		const u32 cap = (u32)ctx->npix;
+		if ((rc = ugrt_buf_reserve(ctx, ctx->dsort, (size_t)cap * 12)))
+			return rc;
+		u32 *k0 = (u32 *)ctx->dsort.p, *k1 = k0 + cap, *l1 = k1 + cap;
+		if ((rc = ugrt_dda_sort_keys_launch(ctx, g, d_rays, list, dcount, cap, k0)))
+			return rc;
+		int bits = 3, cb = 1;
+		while ((1ull << cb) < (unsigned long long)g.dims[0] * g.dims[1] * g.dims[2])
+			cb++;
+		bits += cb;
+		if (bits > 24)
+			return ugrt_fail(UGRT_EINVAL, "trace_dda: dda_sort needs a grid of at most 2^21 cells");
+		if ((rc = ugrt_prim_sort_pairs(ctx, k0, k1, list, l1, cap, bits, dcount)))
+			return rc;
+		list = l1;
+	}
+	if (kernel == 0) {
+		// window kernel (ugrt_dda_walk.hip)
+		const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
+		if ((rc = ugrt_buf_reserve(ctx, ctx->ubitmap, ((size_t)ncell + 63) / 64 * 8 + 8)))
+			return rc;
+		if (counting)
+			UGRT_HIP(hipMemsetAsync(dc, 0, DS_END * sizeof(unsigned long long), ctx->stream));
+		if ((rc = ugrt_dda_walk_launch(ctx, g, d_value_list, d_span, d_offset, (u32 *)ctx->ubitmap.p, d_vertlist, d_trilist, rec,
+					       d_rays, (const u32 *)list, (const u32 *)dcount, d_hit_t, d_hit_id,
+					       counting ? dc : (unsigned long long *)nullptr, counting, DDA_RPW, CULL_MIN, blocks)))
+			return rc;
+		if (counting) {
+			unsigned long long h[DS_END];
+			UGRT_HIP(hipMemcpyAsync(h, dc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+			UGRT_HIP(hipStreamSynchronize(ctx->stream));
+			ctx->stats[3] = h[0];
+			ctx->stats[4] = h[1];
+			ctx->stats[5] = h[2];
+			for (int i = 0; i < UGRT_DDA_STATS; i++)
+				ctx->dda_stats[i] = DS_ITER + i < DS_END ? h[DS_ITER + i] : 0ull;
+			return UGRT_OK;
+		}
+		ugrt_prof_end(ctx, UGRT_ST_TRACE_DDA);
+		return UGRT_OK;
+	}
 #define UGRT_LAUNCH_DDA(CNTV, RECV, DC)                                                                               \
 	do {                                                                                                          \
 		if (beam)                                                                                             \

@@ -1,0 +1,571 @@
+// ugrt_dda_walk.hip -- reflection bounce, window kernel (round 3; DESIGN.md A13, section 5 "Window DDA").
+//
+// Same specification and the same arithmetic as k_trace_dda_ray / k_trace_dda_beam (ugrt_dda.hip): clip, walk the
+// cells front to back (Amanatides & Woo), per cell every triangle in ascending id with the reference's
+// Moller-Trumbore (signed t, 0 < t < best), stop at the first cell whose best hit lies before the cell's exit.
+// What the round-2 beam kernel spent its time on, by its own phase stamps (profiles/r02_dda_phases.json), and
+// what this kernel does about it:
+//   * 83 % of the cells a ray visits are EMPTY, and 60 % of a wave's blocks of 8 steps hold no triangle for any of
+//     its 64 rays, yet every step fetched span[] and offset[] of its cell (1024 divergent 4-byte gathers per wave
+//     and block: 31 % of all wave cycles, bound by the CU's address path).  Here the walk consults a BITMAP of the
+//     occupied cells (1 bit per cell, 128 KB for 128x128x64: cache resident, neighbouring rays share its lines); a
+//     window of 8 steps without an occupied cell costs the plan and one short round trip, and the headers are
+//     fetched per JOB (one lane per distinct cell), not per ray and step.
+//   * A ray's stop test `best_t <= exit of the cell` only has to be evaluated where something can change: tnext
+//     grows monotonically along the walk and best_t changes only in occupied cells, so "the ray stopped in one of
+//     the empty cells before cell k" is the single comparison best_t <= t_in(k).  Empty steps therefore cost no
+//     LDS traffic at all (the beam kernel re-read six plan words per ray and step: its "rest" phase, 15 %).
+//   * Exact tests ran one broadcast triangle per round with ~18-24 of 64 lanes busy.  Here lanes are
+//     (survivor, ray) PAIRS: a job with n <= 32 rays tests floor(64 / n) survivors per round, rays and survivors
+//     come from LDS, closest hits are merged per ray by ds_min_u64 on (t bits << 32 | list position) -- the strict
+//     `<` of the sequential loop in list order.  Lone rays are jobs of one ray (64 triangles per round).
+// Results are bit-identical to the other two kernels and to the oracle (tests/test_gpu_parity.py).
+#include "ugrt_dda.h"
+
+#define WK_AHEAD 8    // steps planned per window
+#define WK_MAXLAG 7   // phase alignment: a ray may wait this many steps for the rays behind it
+#define WK_JOBCAP 128 // jobs listed per pass (a step has at most 64: every pass lists at least one whole step)
+#define WK_NONE 0xFFFFFFFFu
+
+// statistics of the counting variant: counters[0..2] = tests, cells, rays (the algorithmic-byte formula), then
+enum { WS_WINDOWS = 3, WS_JOBS, WS_JOB_RAYS, WS_CULL_BATCHES, WS_CULL_TESTS, WS_ROUNDS, WS_ROUND_PAIRS, WS_EMPTY_WINDOWS,
+       WS_HIST /* 16: waves by log2(cycles / 4096) */, WS_SUM_CYCLES = WS_HIST + 16, WS_MAX_CYCLES,
+       WS_PHASE /* 8: plan+bitmap, job list+headers, operand arrival, box, cull, exact rounds, settle, rest */,
+       WS_PHASE_HEAVY = WS_PHASE + 8 /* the same for waves of >= 2^19 cycles, then their count, rounds, jobs, windows */,
+       WS_END = WS_PHASE_HEAVY + 12 };
+static_assert(WS_END <= 3 + UGRT_DDA_STATS, "window kernel statistics");
+
+// occupancy bitmap: bit c of the word array = span[c] != 0 (a wave writes one 64-bit word per 64 cells)
+__global__ __launch_bounds__(256) void k_cell_bitmap(const u32 *__restrict__ span, u32 C, u32 *__restrict__ bitmap)
+{
+	const u32 lane = threadIdx.x & 63u;
+	for (u32 base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; base < C; base += gridDim.x * 256u) {
+		const u32 c = base + lane;
+		const bool ne = c < C && span[c] != 0u;
+		const unsigned long long m = __ballot(ne);
+		if (lane == 0u) {
+			bitmap[base >> 5] = (u32)m;
+			bitmap[(base >> 5) + 1u] = (u32)(m >> 32);
+		}
+	}
+}
+
+// key of the optional ray sort (SURVEY 8f.2 as written: entry cell, then direction octant)
+__global__ __launch_bounds__(256) void k_dda_sort_keys(DGrid g, const float *__restrict__ rays, const u32 *__restrict__ list,
+						       const u32 *__restrict__ count_p, u32 cap, u32 *__restrict__ keys)
+{
+	const u32 i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= cap)
+		return;
+	if (i >= *count_p) {
+		keys[i] = 0xFFFFFFFFu >> 8; // padding sorts last (the sort runs over the capacity)
+		return;
+	}
+	const u32 p = list[i];
+	float o[3], d[3], tenter = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		o[k] = rays[p * 6 + k];
+		d[k] = rays[p * 6 + 3 + k];
+	}
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		if (d[k] != 0.0f) {
+			const float inv = 1.0f / d[k];
+			const float lo = g.lo[k], hi = g.lo[k] + g.cs[k] * (float)g.dims[k];
+			const float t0 = (lo - o[k]) * inv, t1 = (hi - o[k]) * inv;
+			const float tn = t0 < t1 ? t0 : t1;
+			tenter = tn > tenter ? tn : tenter;
+		}
+	u32 cell = 0;
+#pragma unroll
+	for (int k = 0; k < 3; k++)
+		cell = cell * (u32)g.dims[k] + (u32)d_dcell(g, k, o[k] + tenter * d[k]);
+	const u32 oct = (d[0] < 0.0f ? 1u : 0u) | (d[1] < 0.0f ? 2u : 0u) | (d[2] < 0.0f ? 4u : 0u);
+	keys[i] = (cell << 3) | oct;
+}
+
+#define WK_STAMP(PH)                                                          \
+	do {                                                                  \
+		if (COUNT) {                                                  \
+			const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+			ph[PH] += now_ - tstamp;                              \
+			tstamp = now_;                                        \
+		}                                                             \
+	} while (0)
+
+template <bool COUNT, bool REC>
+__global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__restrict__ value_list,
+							const u32 *__restrict__ span, const u32 *__restrict__ offset,
+							const u32 *__restrict__ bitmap, const float *__restrict__ verts,
+							const int *__restrict__ tris, const float4 *__restrict__ rec,
+							const float *__restrict__ rays, const u32 *__restrict__ list,
+							const u32 *__restrict__ count_p, float *__restrict__ hit_t,
+							int *__restrict__ hit_id, unsigned long long *__restrict__ counters,
+							u32 RPW, u32 CULL_MIN, u32 *__restrict__ ticket)
+{
+	__shared__ u32 s_cell[WK_AHEAD][64];    // cell of (step, ray); written for occupied cells only
+	__shared__ float s_tnext[WK_AHEAD][64]; // exit parameter of (step, ray); the entry of step q is the exit of q - 1
+	__shared__ __attribute__((aligned(16))) float s_surv[64 * TRI_STRIDE]; // survivors of a batch: 9 floats + list position
+	__shared__ __attribute__((aligned(16))) float s_ray[64 * 8];           // the group's rays {o, d}
+	__shared__ unsigned long long s_best[64];                            // per ray: closest hit of the running job
+	__shared__ u32 s_jcell[WK_JOBCAP], s_jbase[WK_JOBCAP], s_jlen[WK_JOBCAP];
+	__shared__ unsigned char s_jq[WK_JOBCAP];
+	__shared__ unsigned char s_rank[64]; // k-th ray of the running job
+	const int lane = threadIdx.x;
+	const u32 count = *count_p;
+	const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
+	for (u32 grp = blockIdx.x; (unsigned long long)grp * RPW < count;) {
+		const unsigned long long clk0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+		unsigned long long tstamp = clk0, ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		const u32 slot = grp * RPW + (u32)lane;
+		const bool inb = (u32)lane < RPW && slot < count;
+		const int p = inb ? (int)list[slot] : 0;
+		u32 n_cells = 0, n_tests = 0;
+		u32 st_win = 0, st_empty = 0, st_jobs = 0, st_jrays = 0, st_cb = 0, st_ct = 0, st_rounds = 0, st_pairs = 0;
+		float tmax[3] = { 0, 0, 0 }, tdelta[3] = { 0, 0, 0 };
+		int c[3] = { 0, 0, 0 }, step[3] = { 0, 0, 0 };
+		float best_t = 3.0e38f, tcur = 0.0f;
+		u32 best_ref = WK_NONE; // list position of the closest hit so far (value_list[best_ref] is its triangle)
+		bool walking = false, hitstop = false;
+		// set-up: exactly the arithmetic of the per-ray kernel and of the specification
+		{
+			float o[3] = { 0, 0, 0 }, d[3] = { 0, 0, 0 };
+			if (inb) {
+				float tenter = 0.0f, texit = 3.0e38f;
+#pragma unroll
+				for (int k = 0; k < 3; k++) {
+					o[k] = rays[p * 6 + k];
+					d[k] = rays[p * 6 + 3 + k];
+				}
+#pragma unroll
+				for (int k = 0; k < 3; k++) {
+					float lo = g.lo[k], hi = g.lo[k] + g.cs[k] * (float)g.dims[k];
+					if (d[k] != 0.0f) {
+						float inv = 1.0f / d[k];
+						float t0 = (lo - o[k]) * inv, t1 = (hi - o[k]) * inv;
+						if (t0 > t1) {
+							float s = t0;
+							t0 = t1;
+							t1 = s;
+						}
+						if (t0 > tenter)
+							tenter = t0;
+						if (t1 < texit)
+							texit = t1;
+					} else if (o[k] < lo || o[k] > hi) {
+						texit = -1.0f;
+					}
+				}
+				if (tenter <= texit) {
+					walking = true;
+					tcur = tenter;
+#pragma unroll
+					for (int k = 0; k < 3; k++) {
+						float pe = o[k] + tenter * d[k];
+						c[k] = d_dcell(g, k, pe);
+						if (d[k] > 0.0f) {
+							step[k] = 1;
+							tmax[k] = ((g.lo[k] + (float)(c[k] + 1) * g.cs[k]) - o[k]) / d[k];
+							tdelta[k] = g.cs[k] / d[k];
+						} else if (d[k] < 0.0f) {
+							step[k] = -1;
+							tmax[k] = ((g.lo[k] + (float)c[k] * g.cs[k]) - o[k]) / d[k];
+							tdelta[k] = -g.cs[k] / d[k];
+						} else {
+							step[k] = 0;
+							tmax[k] = 3.0e38f;
+							tdelta[k] = 3.0e38f;
+						}
+					}
+				}
+			}
+			// the rays live in LDS from here on: the walk does not need them, the jobs read them by ray index
+			*reinterpret_cast<float4 *>(&s_ray[lane * 8]) = make_float4(o[0], o[1], o[2], d[0]);
+			*reinterpret_cast<float2 *>(&s_ray[lane * 8 + 4]) = make_float2(d[1], d[2]);
+			s_best[lane] = ~0ull;
+		}
+		// Phase alignment (as in the beam kernel): w = sx*cx + sy*cy + sz*cz grows by one per step, rays of one octant
+		// can only meet in a cell at equal w, so rays up to WK_MAXLAG steps ahead of the rearmost ray of their
+		// cluster wait that many steps.  (Waiting changes no result.)
+		int lag = 0;
+		{
+			const int w0 = step[0] * c[0] + step[1] * c[1] + step[2] * c[2];
+			bool open = walking;
+			for (int pass = 0; pass < 4 && __ballot(open) != 0ull; pass++) {
+				const int wmin = d_wave_imin(open ? w0 : 0x7FFFFFFF);
+				if (open && w0 - wmin <= WK_MAXLAG) {
+					lag = w0 - wmin;
+					open = false;
+				}
+			}
+		}
+		// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
+		int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3;
+		__syncthreads();
+		while (__ballot(walking) != 0ull) {
+			if (COUNT)
+				st_win++;
+			WK_STAMP(7);
+			// 1. plan WK_AHEAD steps (registers only) and look their cells up in the occupancy bitmap
+			const float tstart = tcur;
+			u32 pcell[WK_AHEAD], vmask = 0u, nem = 0u;
+			float ptn[WK_AHEAD];
+			bool ended = false;
+			{
+				bool planning = walking;
+#pragma unroll
+				for (int q = 0; q < WK_AHEAD; q++) {
+					pcell[q] = 0u;
+					if (planning && lag > 0) {
+						lag--;
+					} else if (planning) {
+						vmask |= 1u << q;
+						pcell[q] = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
+						int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
+						tcur = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
+						bool outside;
+						if (ax == 0) {
+							c[0] += step[0];
+							outside = step[0] == 0 || c[0] < 0 || c[0] >= g.dims[0];
+							tmax[0] += tdelta[0];
+						} else if (ax == 1) {
+							c[1] += step[1];
+							outside = step[1] == 0 || c[1] < 0 || c[1] >= g.dims[1];
+							tmax[1] += tdelta[1];
+						} else {
+							c[2] += step[2];
+							outside = step[2] == 0 || c[2] < 0 || c[2] >= g.dims[2];
+							tmax[2] += tdelta[2];
+						}
+						if (outside || --guard <= 0) {
+							ended = true; // the walk ends after this cell unless it ends there with a hit
+							planning = false;
+						} else if (best_ref != WK_NONE && best_t <= tcur) {
+							planning = false; // the hit carried along lies before this cell's exit: the ray stops here at the latest
+						}
+					}
+					ptn[q] = tcur;
+				}
+				u32 bw[WK_AHEAD];
+#pragma unroll
+				for (int q = 0; q < WK_AHEAD; q++)
+					bw[q] = bitmap[min(pcell[q], ncell - 1u) >> 5];
+#pragma unroll
+				for (int q = 0; q < WK_AHEAD; q++)
+					nem |= (((vmask >> q) & (bw[q] >> (pcell[q] & 31u))) & 1u) << q;
+			}
+			if (COUNT) {
+				// (every slot's exit is needed to find the step a ray stopped in)
+#pragma unroll
+				for (int q = 0; q < WK_AHEAD; q++)
+					s_tnext[q][lane] = ptn[q];
+			}
+			u32 qmask = 0u; // steps with an occupied cell on any ray
+#pragma unroll
+			for (int q = 0; q < WK_AHEAD; q++)
+				qmask |= (__ballot((nem >> q) & 1u) != 0ull ? 1u : 0u) << q;
+			WK_STAMP(0);
+			if (qmask != 0u) {
+				if (!COUNT) {
+#pragma unroll
+					for (int q = 0; q < WK_AHEAD; q++)
+						s_tnext[q][lane] = ptn[q];
+				}
+#pragma unroll
+				for (int q = 0; q < WK_AHEAD; q++)
+					if ((nem >> q) & 1u)
+						s_cell[q][lane] = pcell[q];
+				__syncthreads();
+				// 2. jobs = the distinct occupied cells of every step (rays that are in phase meet in the same step), listed
+				//    in step order, at most WK_JOBCAP per pass
+				u32 qnext = 0u;
+				while (qnext < (u32)WK_AHEAD) {
+					u32 njobs = 0u;
+					for (; qnext < (u32)WK_AHEAD && njobs <= (u32)(WK_JOBCAP - 64); qnext++) {
+						if (!((qmask >> qnext) & 1u))
+							continue;
+						const bool part = walking && ((nem >> qnext) & 1u);
+						const u32 cell = part ? s_cell[qnext][lane] : 0u;
+						unsigned long long todo = __ballot(part);
+						while (todo != 0ull) {
+							const int l = (int)__builtin_ctzll(todo);
+							const u32 X = (u32)__builtin_amdgcn_readlane((int)cell, l);
+							todo &= ~__ballot(part && cell == X);
+							if (lane == 0) {
+								s_jcell[njobs] = X;
+								s_jq[njobs] = (unsigned char)qnext;
+							}
+							njobs++;
+						}
+					}
+					__syncthreads();
+					// the headers of the jobs' cells: one lane per job
+					for (u32 j = (u32)lane; j < njobs; j += 64u) {
+						const u32 X = s_jcell[j];
+						s_jbase[j] = offset[X];
+						s_jlen[j] = span[X];
+					}
+					__syncthreads();
+					WK_STAMP(1);
+					// 3. the jobs in step order; the triangle ids of job j+2 and the records of job j+1 are in flight while
+					//    job j is tested (every lane loads, beyond the end of a list the last triangle again, and past the
+					//    last job the last job again: the number of loads in flight does not depend on the data)
+#define WK_JOB_ID(J) value_list[s_jbase[J] + min((u32)lane, s_jlen[J] - 1u)]
+					u32 idA = 0u, fN = 0u;
+					float rN[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+					if (njobs > 0u) {
+						fN = WK_JOB_ID(0u);
+						idA = WK_JOB_ID(min(1u, njobs - 1u));
+						d_load_record<REC>(rec, verts, tris, fN, rN);
+					}
+#pragma unroll 1
+					for (u32 j = 0; j < njobs; j++) {
+						u32 f0 = fN;
+						float r0[9];
+#pragma unroll
+						for (int k = 0; k < 9; k++)
+							r0[k] = rN[k];
+						// this job's operands must have arrived here, before the next loads are issued
+						asm volatile("" : "+v"(f0), "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "+v"(r0[4]), "+v"(r0[5]),
+							     "+v"(r0[6]), "+v"(r0[7]), "+v"(r0[8]), "+v"(idA));
+						WK_STAMP(2);
+						fN = idA;
+						d_load_record<REC>(rec, verts, tris, fN, rN);
+						idA = WK_JOB_ID(min(j + 2u, njobs - 1u));
+						const u32 X = s_jcell[j], q = s_jq[j], base = s_jbase[j], S = s_jlen[j];
+						bool in = walking && ((nem >> q) & 1u) && s_cell[q][lane] == X;
+						float tin = 0.0f;
+						if (in) {
+							// the ray may have stopped in one of the empty cells since its last occupied one: tnext grows along
+							// the walk and best_t has not changed since, so that is the one comparison with this cell's entry
+							tin = q != 0u ? s_tnext[q - 1u][lane] : tstart;
+							if (best_ref != WK_NONE && best_t <= tin) {
+								if (COUNT) { // the step it stopped in: the first whose exit is not before the hit
+									u32 qs = 0u;
+									while (!((vmask >> qs) & 1u) || !(best_t <= s_tnext[qs][lane]))
+										qs++;
+									n_cells += (u32)__popc(vmask & ((2u << qs) - 1u));
+								}
+								hitstop = true;
+								walking = false;
+								in = false;
+							}
+						}
+						const unsigned long long grpm = __ballot(in);
+						if (grpm == 0ull)
+							continue; // every ray of the job ended in an earlier step of this window
+						const u32 n = (u32)__popcll(grpm);
+						if (COUNT) {
+							st_jobs++;
+							st_jrays += n;
+							if (in)
+								n_tests += S;
+						}
+						const bool use_cull = S >= CULL_MIN;
+						BeamBox bx;
+						if (use_cull) { // the bundle box is formed from the rays' own lanes
+							const float4 a = *reinterpret_cast<const float4 *>(&s_ray[lane * 8]);
+							const float2 b = *reinterpret_cast<const float2 *>(&s_ray[lane * 8 + 4]);
+							const float o[3] = { a.x, a.y, a.z }, d[3] = { a.w, b.x, b.y };
+							bx = d_beam_box(o, d, tin, in);
+						}
+						WK_STAMP(3);
+						// lanes as (survivor, ray) pairs: pair slot `lane` = survivor lane / n, ray number lane % n of the job
+						// (more than 32 rays: one survivor per round)
+						const u32 mper = 64u / n;
+						if (in)
+							s_rank[d_rank_in_mask(grpm)] = (unsigned char)lane;
+						__syncthreads();
+						const u32 my_si = (u32)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)n));
+						const u32 prl = s_rank[(u32)lane - my_si * n];
+						float po[3], pd[3];
+						{
+							const float4 a = *reinterpret_cast<const float4 *>(&s_ray[prl * 8u]);
+							const float2 b = *reinterpret_cast<const float2 *>(&s_ray[prl * 8u + 4u]);
+							po[0] = a.x, po[1] = a.y, po[2] = a.z, pd[0] = a.w, pd[1] = b.x, pd[2] = b.y;
+						}
+						for (u32 b = 0; b < S; b += 64u) {
+							const bool have = b + (u32)lane < S;
+							float r9[9];
+#pragma unroll
+							for (int k = 0; k < 9; k++)
+								r9[k] = r0[k];
+							if (b != 0u && have) { // lists beyond 64 triangles: the later batches are fetched here
+								const u32 f = value_list[base + b + (u32)lane];
+								d_load_record<REC>(rec, verts, tris, f, r9);
+							}
+							bool keep = have;
+							if (use_cull && have)
+								keep = !d_cull_beam(&r9[0], &r9[3], &r9[6], bx);
+							const unsigned long long m = __ballot(keep);
+							WK_STAMP(4);
+							if (COUNT && use_cull) {
+								st_cb++;
+								st_ct += (u32)__popcll(__ballot(have));
+							}
+							if (m == 0ull)
+								continue;
+							const u32 ks = (u32)__popcll(m);
+							if (keep) { // survivors in list order
+								float4 *dst = reinterpret_cast<float4 *>(&s_surv[d_rank_in_mask(m) * TRI_STRIDE]);
+								dst[0] = make_float4(r9[0], r9[1], r9[2], r9[3]);
+								dst[1] = make_float4(r9[4], r9[5], r9[6], r9[7]);
+								dst[2] = make_float4(r9[8], __uint_as_float(base + b + (u32)lane), 0.0f, 0.0f);
+							}
+							__syncthreads();
+							for (u32 r = 0; r < ks; r += mper) {
+								const bool act = my_si < mper && r + my_si < ks;
+								if (act) {
+									const float4 *src = reinterpret_cast<const float4 *>(&s_surv[(r + my_si) * TRI_STRIDE]);
+									const float4 a = src[0], e = src[1], h = src[2];
+									const float tv[3] = { po[0] - a.x, po[1] - a.y, po[2] - a.z };
+									const float e1[3] = { a.w, e.x, e.y }, e2[3] = { e.z, e.w, h.x };
+									float t;
+									// closest hit per ray: (t, list position) ordered as the sequential loop's strict `<` in list order
+									if (d_mt_core(tv, e1, e2, pd, &t) && t > 0.0f)
+										atomicMin(&s_best[prl], ((unsigned long long)__float_as_uint(t) << 32) |
+														 (unsigned long long)__float_as_uint(h.y));
+								}
+								if (COUNT) {
+									st_rounds++;
+									st_pairs += (u32)__popcll(__ballot(act));
+								}
+							}
+							__syncthreads(); // the survivors are read before the next batch overwrites them
+							WK_STAMP(5);
+						}
+						// the job is the step of its rays: merge its closest hit (strict <: an equal hit of an earlier cell
+						// stays) and test the stop rule against the cell's exit
+						if (in) {
+							const unsigned long long k = s_best[lane];
+							if (k != ~0ull) {
+								s_best[lane] = ~0ull;
+								const float jt = __uint_as_float((u32)(k >> 32));
+								if (jt < best_t) {
+									best_t = jt;
+									best_ref = (u32)k;
+								}
+							}
+							if (best_ref != WK_NONE && best_t <= s_tnext[q][lane]) {
+								if (COUNT)
+									n_cells += (u32)__popc(vmask & ((2u << q) - 1u));
+								hitstop = true;
+								walking = false;
+							}
+						}
+						WK_STAMP(6);
+					}
+#undef WK_JOB_ID
+				}
+			} else if (COUNT) {
+				st_empty++;
+			}
+			// 4. the end of the window: the stop rule over the empty cells behind the ray's last occupied one, and the
+			//    end of the walk
+			if (walking) {
+				if (best_ref != WK_NONE && best_t <= tcur) {
+					if (COUNT) {
+						u32 qs = 0u;
+						while (!((vmask >> qs) & 1u) || !(best_t <= s_tnext[qs][lane]))
+							qs++;
+						n_cells += (u32)__popc(vmask & ((2u << qs) - 1u));
+					}
+					hitstop = true;
+					walking = false;
+				} else {
+					if (COUNT)
+						n_cells += (u32)__popc(vmask);
+					if (ended)
+						walking = false;
+				}
+			}
+			if (COUNT)
+				__syncthreads(); // (s_tnext is rewritten by the next window's plan)
+		}
+		if (inb) {
+			hit_t[p] = hitstop ? best_t : -1.0f;
+			hit_id[p] = hitstop ? (int)value_list[best_ref] : -2;
+		}
+		if (COUNT) {
+			if (inb) {
+				if (n_tests)
+					atomicAdd(&counters[0], (unsigned long long)n_tests);
+				if (n_cells)
+					atomicAdd(&counters[1], (unsigned long long)n_cells);
+				atomicAdd(&counters[2], 1ull);
+			}
+			if (lane == 0) { // wave-uniform counts
+				atomicAdd(&counters[WS_WINDOWS], (unsigned long long)st_win);
+				atomicAdd(&counters[WS_EMPTY_WINDOWS], (unsigned long long)st_empty);
+				atomicAdd(&counters[WS_JOBS], (unsigned long long)st_jobs);
+				atomicAdd(&counters[WS_JOB_RAYS], (unsigned long long)st_jrays);
+				atomicAdd(&counters[WS_CULL_BATCHES], (unsigned long long)st_cb);
+				atomicAdd(&counters[WS_CULL_TESTS], (unsigned long long)st_ct);
+				atomicAdd(&counters[WS_ROUNDS], (unsigned long long)st_rounds);
+				atomicAdd(&counters[WS_ROUND_PAIRS], (unsigned long long)st_pairs);
+				const unsigned long long cyc = __builtin_amdgcn_s_memtime() - clk0;
+				int bucket = 0;
+				while (bucket < 15 && (cyc >> (12 + bucket)) > 1ull)
+					bucket++;
+				atomicAdd(&counters[WS_HIST + bucket], 1ull);
+				atomicAdd(&counters[WS_SUM_CYCLES], cyc);
+				for (int k = 0; k < 8; k++)
+					atomicAdd(&counters[WS_PHASE + k], ph[k]);
+				if (cyc >= (1ull << 19)) {
+					for (int k = 0; k < 8; k++)
+						atomicAdd(&counters[WS_PHASE_HEAVY + k], ph[k]);
+					atomicAdd(&counters[WS_PHASE_HEAVY + 8], 1ull);
+					atomicAdd(&counters[WS_PHASE_HEAVY + 9], (unsigned long long)st_rounds);
+					atomicAdd(&counters[WS_PHASE_HEAVY + 10], (unsigned long long)st_jobs);
+					atomicAdd(&counters[WS_PHASE_HEAVY + 11], (unsigned long long)st_win);
+				}
+				atomicMax(&counters[WS_MAX_CYCLES], cyc);
+			}
+		}
+		__syncthreads(); // the next group's rays overwrite s_ray
+		if (lane == 0)
+			grp = gridDim.x + atomicAdd(ticket, 1u);
+		grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
+	} // groups
+}
+
+// launched by ugrt_trace_dda (ugrt_dda.hip) behind k_dda_prepare; `bitmap` has (ncell + 63) / 64 * 2 words
+int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
+			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
+			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
+			 bool counting, u32 RPW, u32 CULL_MIN, int blocks)
+{
+	const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
+	const u32 bblocks = (ncell + 255u) / 256u;
+	hipLaunchKernelGGL(k_cell_bitmap, dim3(bblocks < 2048u ? bblocks : 2048u), dim3(256), 0, ctx->stream, d_span, ncell, bitmap);
+	UGRT_HIP(hipGetLastError());
+	u32 *ticket = ctx->d_small + UGRT_DSMALL_TICKET;
+#define WK_LAUNCH(CNTV, RECV)                                                                                          \
+	hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
+			   d_offset, (const u32 *)bitmap, d_vertlist, d_trilist, rec, d_rays, list, dcount, d_hit_t, d_hit_id, \
+			   counters, RPW, CULL_MIN, ticket)
+	if (counting) {
+		if (rec)
+			WK_LAUNCH(true, true);
+		else
+			WK_LAUNCH(true, false);
+	} else {
+		if (rec)
+			WK_LAUNCH(false, true);
+		else
+			WK_LAUNCH(false, false);
+	}
+#undef WK_LAUNCH
+	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}
+
+// the optional ray sort: keys of the listed rays (entry cell << 3 | octant); `cap` = entries of the list buffer
+int ugrt_dda_sort_keys_launch(ugrt_ctx *ctx, const DGrid &g, const float *d_rays, const u32 *list, const u32 *dcount, u32 cap,
+			      u32 *keys)
+{
+	hipLaunchKernelGGL(k_dda_sort_keys, dim3((cap + 255u) / 256u), dim3(256), 0, ctx->stream, g, d_rays, list, dcount, cap, keys);
+	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}

@@ -1610,12 +1610,14 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 				gb <<= 1;
 			Gcap = (u32)maxg;
 			G = gb < Gcap ? gb : Gcap; // only its bit width is used below
-			hipLaunchKernelGGL(k_pair_check, dim3(1), dim3(1), 0, st, (const u32 *)pcount, (u32)cap,
+			// launch size of the per-pair kernels; the check is made against it, not against the (larger) buffers:
+			// the sort and the run kernel work on P pairs, so a count between the two would lose candidates
+			const size_t lp = (size_t)ctx->est_pairs + ctx->est_pairs / 4 + 65536;
+			P = (u32)(lp < cap ? lp : cap);
+			hipLaunchKernelGGL(k_pair_check, dim3(1), dim3(1), 0, st, (const u32 *)pcount, P,
 					   (const u32 *)(gincl + (C - 1)), G, pg, status, report);
 			UGRT_HIP(hipGetLastError());
 			pgp = pg; // (the report travels to the host with the copy behind the exact pass)
-			const size_t lp = (size_t)ctx->est_pairs + ctx->est_pairs / 4 + 65536;
-			P = (u32)(lp < cap ? lp : cap); // launch size of the per-pair kernels
 			xcap = (ctx->est_beams + ctx->est_beams / 4u + 64u + P / XSEG) * (beam / 64u);
 			ctx->shadow_async_pending = true;
 			break;

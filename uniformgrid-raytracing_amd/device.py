@@ -257,15 +257,22 @@ class Context:
         check(lib.ugrt_stats_primary(self._h, a, 16))
         return dict(zip(self.PRIMARY_STATS, list(a)))
 
-    def stats_dda(self):
-        """Work sharing of the beam kernel's last counting launch (a FLAG_COUNT_WORK context)."""
+    WALK_STATS = ("windows", "jobs", "job_rays", "cull_batches", "cull_tests", "rounds", "round_pairs", "empty_windows")
+
+    def stats_dda(self, kernel=0):
+        """Work sharing of the bounce kernel's last counting launch (a FLAG_COUNT_WORK context); `kernel` = the
+        "dda_kernel" option it ran with (0 window kernel, 2 beam kernel of round 2: the counters' meanings differ)."""
         a = (C.c_ulonglong * 46)()
         check(lib.ugrt_stats_dda(self._h, a, 46))
-        d = dict(zip(self.DDA_STATS, list(a)[:8]))
+        walk = kernel == 0
+        d = dict(zip(self.WALK_STATS if walk else self.DDA_STATS, list(a)[:8]))
         d["waves_by_log2_cycles_over_4096"] = list(a)[8:24]
         d["cycles_sum"], d["cycles_max"] = a[24], a[25]
-        d["phase_cycles"] = dict(zip(("plan_headers", "job_list", "operand_arrival", "box", "cull", "exact_rounds",
-                                      "lone_rays", "rest"), list(a)[26:34]))
-        d["heavy_waves"] = dict(zip(("plan_headers", "job_list", "operand_arrival", "box", "cull", "exact_rounds",
-                                     "lone_rays", "rest", "waves", "rounds", "groups", "iterations"), list(a)[34:46]))
+        phases = (("plan_bitmap", "job_list_headers", "operand_arrival", "box", "cull", "exact_rounds", "settle", "rest")
+                  if walk else ("plan_headers", "job_list", "operand_arrival", "box", "cull", "exact_rounds", "lone_rays",
+                                "rest"))
+        d["phase_cycles"] = dict(zip(phases, list(a)[26:34]))
+        d["heavy_waves" if not walk else "waves_of_2e19_cycles_or_more"] = dict(
+            zip(phases + ("waves", "rounds", "jobs" if walk else "groups", "windows" if walk else "iterations"),
+                list(a)[34:46]))
         return d

@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--no-static-geometry", action="store_true",
                     help="rebuild the per-triangle records in every grid build, as a caller that rewrites the vertex array "
                          "behind the library's back must (default: UGRT_FLAG_STATIC_GEOMETRY, the renderer is the only writer)")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=True, help="(the default; kept for older command lines)")
     ap.add_argument("--no-verify", dest="verify", action="store_false",
                     help="skip the check behind the timed region (default: on).  N = 1: the buffers every renderer in flight "
                          "holds from its last frame (image, shadow flags, ids, t, normals, directions, bounce hits) are "

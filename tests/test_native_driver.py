@@ -80,6 +80,27 @@ def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect
 
 
 @pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself (it never touches
+    the GPU), relays rank 0's line and their exit code.  Rehearsal on one GPU (gloo, host staging), verified against
+    the single-context frame."""
+    import json
+    import sys
+
+    env = dict(os.environ, UGRT_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--cpu-seconds", "0",
+           "--repeats", "0", "--scale", "0.05", "--width", "640", "--height", "360", "--balance-rounds", "1"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["verified_against_single_context_frame"] is True
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--shard-builds"], ["--config3"]])
 def test_bench_two_ranks_on_one_gpu_gather_the_right_image(extra):
     """The N > 1 path of bench.py end to end with the real kernels: two ranks (both on this one GPU, gloo with host

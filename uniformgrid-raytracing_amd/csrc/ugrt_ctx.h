@@ -37,6 +37,7 @@ enum {
 	UGRT_OPT_PRIMARY_WAVES,    // "primary_waves": single-wave workgroups of the primary tracer
 	UGRT_OPT_SHADOW_WAVES,     // "shadow_waves": the same for the two shadow kernels
 	UGRT_OPT_DDA_SORT,         // "dda_sort": 1 = the bounce's ray list is sorted by (entry cell, octant) instead of tile order
+	UGRT_OPT_DDA_BOX,          // "dda_box": window kernel's bundle boxes, 0 = DPP reductions, 1 = LDS atomics
 	UGRT_OPT_COUNT
 };
 
@@ -116,6 +117,8 @@ struct ugrt_ctx {
 	int p0 = 0, npix = 0; // first pixel and pixel count of this context's band
 	Grid grid[3];
 	DevBuf temp;                  // rocPRIM temporary storage
+	DevBuf scan_state;            // own scan: ticket + done counter (64 B), then one epoch-tagged state word per tile
+	u32 scan_epoch = 0;           // tag of the last scan's state words
 	DevBuf rs_state, rs_tmp[2];   // own radix sort: histograms + tickets + look-back words, ping-pong buffers
 	int rs_flip = 0;              // which of rs_state's two histogram blocks the next sort uses (the other one is cleared by it)
 	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
@@ -177,7 +180,7 @@ static inline u32 *ugrt_wide_counter(ugrt_ctx *ctx) { return ctx->d_small + UGRT
 void ugrt_prof_begin(ugrt_ctx *ctx, int stage);
 void ugrt_prof_end(ugrt_ctx *ctx, int stage);
 
-// rocPRIM wrappers (ugrt_prims.hip); all enqueue on ctx->stream
+// prefix sums (ugrt_scan.hip) and the library wrappers (ugrt_prims.hip); all enqueue on ctx->stream
 int ugrt_prim_inclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
 int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n);
 // stable LSD radix sort of (key,value) pairs on key bits [0,end_bit)

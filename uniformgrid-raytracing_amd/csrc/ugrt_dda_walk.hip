@@ -85,6 +85,56 @@ __global__ __launch_bounds__(256) void k_dda_sort_keys(DGrid g, const float *__r
 	keys[i] = (cell << 3) | oct;
 }
 
+// The bundle box of d_beam_box (ugrt_dda.h) with the thirteen wave reductions done by the LDS instead of the DPP
+// path: the rays of the job issue ds_min / ds_max on the order-preserving integer images of their values (13
+// instructions whatever the number of rays; the DPP form is 13 dependent chains of seven steps each).  Same
+// minima and maxima, hence the same box.  s_box: 16 words.
+__device__ __forceinline__ BeamBox d_beam_box_lds(int *s_box, const float *o, const float *d, float tin, bool in, int lane)
+{
+	if (lane < 13)
+		s_box[lane] = lane < 6 ? 0x7FFFFFFF : (int)0x80000000;
+	__syncthreads();
+	if (in) {
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			const int pk = d_ordered(o[k] + tin * d[k]), dk = d_ordered(d[k]);
+			atomicMin(&s_box[k], pk);
+			atomicMax(&s_box[6 + k], pk);
+			atomicMin(&s_box[3 + k], dk);
+			atomicMax(&s_box[9 + k], dk);
+		}
+		atomicMax(&s_box[12], d_ordered(tin));
+	}
+	__syncthreads();
+	BeamBox bx;
+	float on2 = 0.0f, dm2 = 0.0f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		float lo = d_unordered(s_box[k]), hi = d_unordered(s_box[6 + k]);
+		bx.oc[k] = 0.5f * (lo + hi);
+		bx.orad[k] = 0.5f * (hi - lo) * 1.0001f + 7.63e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f;
+		on2 += bx.orad[k] * bx.orad[k];
+		lo = d_unordered(s_box[3 + k]);
+		hi = d_unordered(s_box[9 + k]);
+		bx.dc[k] = 0.5f * (lo + hi);
+		bx.dr[k] = 0.5f * (hi - lo) * 1.0001f + 1e-6f;
+		const float da = fabsf(bx.dc[k]) + bx.dr[k];
+		dm2 += da * da;
+	}
+	const float tmax = d_unordered(s_box[12]);
+	const float on = __builtin_sqrtf(on2) * 1.0001f, dmax = __builtin_sqrtf(dm2) * 1.0001f;
+	bx.reach = (tmax * dmax + on) * 1.001f;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		bx.oc[k] = d_uniform(bx.oc[k]);
+		bx.dc[k] = d_uniform(bx.dc[k]);
+		bx.dr[k] = d_uniform(bx.dr[k]);
+		bx.orad[k] = d_uniform(bx.orad[k]);
+	}
+	bx.reach = d_uniform(bx.reach);
+	return bx;
+}
+
 #define WK_STAMP(PH)                                                          \
 	do {                                                                  \
 		if (COUNT) {                                                  \
@@ -102,7 +152,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 							const float *__restrict__ rays, const u32 *__restrict__ list,
 							const u32 *__restrict__ count_p, float *__restrict__ hit_t,
 							int *__restrict__ hit_id, unsigned long long *__restrict__ counters,
-							u32 RPW, u32 CULL_MIN, u32 *__restrict__ ticket)
+							u32 RPW, u32 CULL_MIN, u32 BOXMODE, u32 *__restrict__ ticket)
 {
 	__shared__ u32 s_cell[WK_AHEAD][64];    // cell of (step, ray); written for occupied cells only
 	__shared__ float s_tnext[WK_AHEAD][64]; // exit parameter of (step, ray); the entry of step q is the exit of q - 1
@@ -112,9 +162,9 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 	__shared__ u32 s_jcell[WK_JOBCAP], s_jbase[WK_JOBCAP], s_jlen[WK_JOBCAP];
 	__shared__ unsigned char s_jq[WK_JOBCAP];
 	__shared__ unsigned char s_rank[64]; // k-th ray of the running job
+	__shared__ int s_box[16];            // bundle box of the running job (ordered-integer minima and maxima)
 	const int lane = threadIdx.x;
 	const u32 count = *count_p;
-	const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
 	for (u32 grp = blockIdx.x; (unsigned long long)grp * RPW < count;) {
 		const unsigned long long clk0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 		unsigned long long tstamp = clk0, ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -123,8 +173,14 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 		const int p = inb ? (int)list[slot] : 0;
 		u32 n_cells = 0, n_tests = 0;
 		u32 st_win = 0, st_empty = 0, st_jobs = 0, st_jrays = 0, st_cb = 0, st_ct = 0, st_rounds = 0, st_pairs = 0;
+		// the walk's state: exit parameters per axis and their increments (the specification's tmax / tdelta), the
+		// current cell as its linear index with the signed index step per axis, and the steps left per axis before the
+		// ray leaves the grid (0 for an axis the ray does not move along: choosing it ends the walk, as in the
+		// specification's `step == 0 || c out of range`)
 		float tmax[3] = { 0, 0, 0 }, tdelta[3] = { 0, 0, 0 };
-		int c[3] = { 0, 0, 0 }, step[3] = { 0, 0, 0 };
+		u32 cidx = 0u, rem[3] = { 0, 0, 0 };
+		int cstep[3] = { 0, 0, 0 };
+		int w0 = 0; // phase of the ray's first cell (alignment below)
 		float best_t = 3.0e38f, tcur = 0.0f;
 		u32 best_ref = WK_NONE; // list position of the closest hit so far (value_list[best_ref] is its triangle)
 		bool walking = false, hitstop = false;
@@ -160,20 +216,25 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 				if (tenter <= texit) {
 					walking = true;
 					tcur = tenter;
+					const int stride[3] = { g.dims[1] * g.dims[2], g.dims[2], 1 };
 #pragma unroll
 					for (int k = 0; k < 3; k++) {
 						float pe = o[k] + tenter * d[k];
-						c[k] = d_dcell(g, k, pe);
+						const int ck = d_dcell(g, k, pe);
+						cidx += (u32)(ck * stride[k]);
 						if (d[k] > 0.0f) {
-							step[k] = 1;
-							tmax[k] = ((g.lo[k] + (float)(c[k] + 1) * g.cs[k]) - o[k]) / d[k];
+							tmax[k] = ((g.lo[k] + (float)(ck + 1) * g.cs[k]) - o[k]) / d[k];
 							tdelta[k] = g.cs[k] / d[k];
+							cstep[k] = stride[k];
+							rem[k] = (u32)(g.dims[k] - 1 - ck);
+							w0 += ck;
 						} else if (d[k] < 0.0f) {
-							step[k] = -1;
-							tmax[k] = ((g.lo[k] + (float)c[k] * g.cs[k]) - o[k]) / d[k];
+							tmax[k] = ((g.lo[k] + (float)ck * g.cs[k]) - o[k]) / d[k];
 							tdelta[k] = -g.cs[k] / d[k];
+							cstep[k] = -stride[k];
+							rem[k] = (u32)ck;
+							w0 -= ck;
 						} else {
-							step[k] = 0;
 							tmax[k] = 3.0e38f;
 							tdelta[k] = 3.0e38f;
 						}
@@ -190,7 +251,6 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 		// cluster wait that many steps.  (Waiting changes no result.)
 		int lag = 0;
 		{
-			const int w0 = step[0] * c[0] + step[1] * c[1] + step[2] * c[2];
 			bool open = walking;
 			for (int pass = 0; pass < 4 && __ballot(open) != 0ull; pass++) {
 				const int wmin = d_wave_imin(open ? w0 : 0x7FFFFFFF);
@@ -200,8 +260,9 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 				}
 			}
 		}
-		// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
-		int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3;
+		// (The specification also bounds the walk by dims[0]+dims[1]+dims[2]+3 steps.  Every step that stays inside
+		// uses up one of the sum(dims) - 3 steps the three axes have left, so that bound is never reached and is not
+		// carried along here.)
 		__syncthreads();
 		while (__ballot(walking) != 0ull) {
 			if (COUNT)
@@ -214,43 +275,39 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			bool ended = false;
 			{
 				bool planning = walking;
+				// A step is written without branches (every lane executes the same ~30 instructions; with the axis
+				// chosen by `if` the three paths ran one after the other and the plan was the kernel's largest phase):
+				// axis = (tx < ty) ? ((tx < tz) ? x : z) : ((ty < tz) ? y : z), as in the specification.
 #pragma unroll
 				for (int q = 0; q < WK_AHEAD; q++) {
-					pcell[q] = 0u;
-					if (planning && lag > 0) {
-						lag--;
-					} else if (planning) {
-						vmask |= 1u << q;
-						pcell[q] = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
-						int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
-						tcur = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
-						bool outside;
-						if (ax == 0) {
-							c[0] += step[0];
-							outside = step[0] == 0 || c[0] < 0 || c[0] >= g.dims[0];
-							tmax[0] += tdelta[0];
-						} else if (ax == 1) {
-							c[1] += step[1];
-							outside = step[1] == 0 || c[1] < 0 || c[1] >= g.dims[1];
-							tmax[1] += tdelta[1];
-						} else {
-							c[2] += step[2];
-							outside = step[2] == 0 || c[2] < 0 || c[2] >= g.dims[2];
-							tmax[2] += tdelta[2];
-						}
-						if (outside || --guard <= 0) {
-							ended = true; // the walk ends after this cell unless it ends there with a hit
-							planning = false;
-						} else if (best_ref != WK_NONE && best_t <= tcur) {
-							planning = false; // the hit carried along lies before this cell's exit: the ray stops here at the latest
-						}
-					}
+					const bool act = planning && lag == 0; // a ray ahead of its cluster waits `lag` steps first
+					lag -= (planning && lag > 0) ? 1 : 0;
+					vmask |= (act ? 1u : 0u) << q;
+					pcell[q] = cidx;
+					const bool xy = tmax[0] < tmax[1], xz = tmax[0] < tmax[2], yz = tmax[1] < tmax[2];
+					const bool a0 = xy && xz, a1 = !xy && yz, a2 = !(a0 || a1);
+					const float tn = a0 ? tmax[0] : (a1 ? tmax[1] : tmax[2]);
+					const u32 left = a0 ? rem[0] : (a1 ? rem[1] : rem[2]);
+					const int cs = a0 ? cstep[0] : (a1 ? cstep[1] : cstep[2]);
+					const bool outside = left == 0u;
+					tcur = act ? tn : tcur;
+					cidx = (act && !outside) ? cidx + (u32)cs : cidx;
+					tmax[0] = (act && a0) ? tmax[0] + tdelta[0] : tmax[0];
+					tmax[1] = (act && a1) ? tmax[1] + tdelta[1] : tmax[1];
+					tmax[2] = (act && a2) ? tmax[2] + tdelta[2] : tmax[2];
+					rem[0] -= (act && a0) ? 1u : 0u; // (wraps when the ray leaves: never read again)
+					rem[1] -= (act && a1) ? 1u : 0u;
+					rem[2] -= (act && a2) ? 1u : 0u;
+					// the walk ends after this cell when the ray leaves the grid, and at the latest here when the hit carried
+					// along lies before this cell's exit
+					ended = ended || (act && outside);
+					planning = planning && !(act && (outside || (best_ref != WK_NONE && best_t <= tn)));
 					ptn[q] = tcur;
 				}
 				u32 bw[WK_AHEAD];
 #pragma unroll
 				for (int q = 0; q < WK_AHEAD; q++)
-					bw[q] = bitmap[min(pcell[q], ncell - 1u) >> 5];
+					bw[q] = bitmap[pcell[q] >> 5];
 #pragma unroll
 				for (int q = 0; q < WK_AHEAD; q++)
 					nem |= (((vmask >> q) & (bw[q] >> (pcell[q] & 31u))) & 1u) << q;
@@ -368,7 +425,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 							const float4 a = *reinterpret_cast<const float4 *>(&s_ray[lane * 8]);
 							const float2 b = *reinterpret_cast<const float2 *>(&s_ray[lane * 8 + 4]);
 							const float o[3] = { a.x, a.y, a.z }, d[3] = { a.w, b.x, b.y };
-							bx = d_beam_box(o, d, tin, in);
+							bx = BOXMODE ? d_beam_box_lds(s_box, o, d, tin, in, lane) : d_beam_box(o, d, tin, in);
 						}
 						WK_STAMP(3);
 						// lanes as (survivor, ray) pairs: pair slot `lane` = survivor lane / n, ray number lane % n of the job
@@ -534,7 +591,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
 			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
 			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
-			 bool counting, u32 RPW, u32 CULL_MIN, int blocks)
+			 bool counting, u32 RPW, u32 CULL_MIN, u32 BOXMODE, int blocks)
 {
 	const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
 	const u32 bblocks = (ncell + 255u) / 256u;
@@ -544,7 +601,7 @@ int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list,
 #define WK_LAUNCH(CNTV, RECV)                                                                                          \
 	hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
 			   d_offset, (const u32 *)bitmap, d_vertlist, d_trilist, rec, d_rays, list, dcount, d_hit_t, d_hit_id, \
-			   counters, RPW, CULL_MIN, ticket)
+			   counters, RPW, CULL_MIN, BOXMODE, ticket)
 	if (counting) {
 		if (rec)
 			WK_LAUNCH(true, true);

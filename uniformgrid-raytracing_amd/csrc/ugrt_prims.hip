@@ -1,7 +1,7 @@
 // ugrt_prims.hip -- the data-parallel primitives of the grid build, on rocPRIM.
 //
 // Replaces the reference's CUDPP 1.1 call sites (cudpp/cudpp.h:426-471):
-//   cudppScan inclusive/exclusive  frustum_grid.h:249,361  -> rocprim::{in,ex}clusive_scan
+//   cudppScan inclusive/exclusive  frustum_grid.h:249,361  -> ugrt_scan.hip (own single-kernel scan)
 //   cudppSort key-value radix      frustum_grid.h:298, decision_data.h:177
 //                                  -> rocprim::radix_sort_pairs (stable LSD radix sort)
 // The reference sorts all 32 key bits although keys < number of cells
@@ -13,31 +13,7 @@
 
 #include "ugrt_ctx.h"
 
-int ugrt_prim_inclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n)
-{
-	if (n == 0)
-		return UGRT_OK;
-	size_t bytes = 0;
-	UGRT_HIP(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<u32>(), ctx->stream));
-	int rc = ugrt_buf_reserve(ctx, ctx->temp, bytes);
-	if (rc)
-		return rc;
-	UGRT_HIP(rocprim::inclusive_scan(ctx->temp.p, bytes, in, out, n, rocprim::plus<u32>(), ctx->stream));
-	return UGRT_OK;
-}
-
-int ugrt_prim_exclusive_scan(ugrt_ctx *ctx, const u32 *in, u32 *out, size_t n)
-{
-	if (n == 0)
-		return UGRT_OK;
-	size_t bytes = 0;
-	UGRT_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<u32>(), ctx->stream));
-	int rc = ugrt_buf_reserve(ctx, ctx->temp, bytes);
-	if (rc)
-		return rc;
-	UGRT_HIP(rocprim::exclusive_scan(ctx->temp.p, bytes, in, out, 0u, n, rocprim::plus<u32>(), ctx->stream));
-	return UGRT_OK;
-}
+// (the prefix sums live in ugrt_scan.hip)
 
 int ugrt_prim_sort_pairs(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
 			 int end_bit, const u32 *n_dev)

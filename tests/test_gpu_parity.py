@@ -217,11 +217,12 @@ def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
     ctx.synchronize()
     uvalue, uspan, uoffset, _ = ctx.grid_ptrs(ugrt.GRID_UNIFORM)
     shapes = [dict(dda_kernel=0), dict(dda_kernel=0, dda_rays_per_wave=16), dict(dda_kernel=0, dda_rays_per_wave=32),
-              dict(dda_kernel=0, dda_cull_min=1), dict(dda_kernel=0, dda_cull_min=1 << 30), dict(dda_kernel=0, dda_sort=1),
+              dict(dda_kernel=0, dda_cull_min=1, dda_cull_work=1), dict(dda_kernel=0, dda_cull_min=1 << 30),
+              dict(dda_kernel=0, dda_cull_work=64), dict(dda_kernel=0, dda_sort=1),
               dict(dda_kernel=0, dda_sort=1, dda_rays_per_wave=24), dict(dda_kernel=0, dda_blocks=7),
               dict(dda_kernel=1), dict(dda_kernel=2), dict(dda_kernel=2, dda_sort=1)]
     for opts in shapes:
-        for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_sort", "dda_blocks"):
+        for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_cull_work", "dda_sort", "dda_blocks"):
             ctx.set_option(k, opts.get(k, -1))
         r.hit_t.fill_(7.0)
         r.hit_id.fill_(7)

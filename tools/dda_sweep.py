@@ -65,17 +65,18 @@ for kernel in (2, 0):  # 2 = beam kernel of round 2, 0 = window kernel
                                     "identical": same})
 ctx.set_option("dda_sort", 0)
 ctx.set_option("dda_kernel", 0)
-for box in (0, 1):  # bundle boxes by DPP reductions / by LDS atomics
-    for rpw in (32, 64):
-        for cull_min in (8, 16, 32):
-            ctx.set_option("dda_box", box)
-            ctx.set_option("dda_rays_per_wave", rpw)
-            ctx.set_option("dda_cull_min", cull_min)
-            ms = run(ctx, r)
-            same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
-            print("kernel 0 box %d rpw %2d cull_min %3d : %.3f ms  identical=%s" % (box, rpw, cull_min, ms, same), flush=True)
-            res["rows"].append({"kernel": 0, "box": box, "rpw": rpw, "cull_min": cull_min, "ms": ms, "identical": same})
-ctx.set_option("dda_box", -1)
+for rpw in (32, 64):
+    for cull_min, cull_work in ((8, 1), (8, 128), (8, 320), (8, 640), (8, 1280), (16, 320), (4, 320)):
+        ctx.set_option("dda_rays_per_wave", rpw)
+        ctx.set_option("dda_cull_min", cull_min)
+        ctx.set_option("dda_cull_work", cull_work)
+        ms = run(ctx, r)
+        same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
+        print("kernel 0 rpw %2d cull_min %3d cull_work %5d : %.3f ms  identical=%s" % (rpw, cull_min, cull_work, ms, same), flush=True)
+        res["rows"].append({"kernel": 0, "rpw": rpw, "cull_min": cull_min, "cull_work": cull_work, "ms": ms, "identical": same})
+ctx.set_option("dda_cull_work", -1)
+ctx.set_option("dda_cull_min", -1)
+ctx.set_option("dda_rays_per_wave", -1)
 # work counters
 cctx, cr = make(ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_COUNT_WORK)
 for k, sort in ((1, 0), (2, 0), (0, 0), (0, 1)):

@@ -37,7 +37,7 @@ enum {
 	UGRT_OPT_PRIMARY_WAVES,    // "primary_waves": single-wave workgroups of the primary tracer
 	UGRT_OPT_SHADOW_WAVES,     // "shadow_waves": the same for the two shadow kernels
 	UGRT_OPT_DDA_SORT,         // "dda_sort": 1 = the bounce's ray list is sorted by (entry cell, octant) instead of tile order
-	UGRT_OPT_DDA_BOX,          // "dda_box": window kernel's bundle boxes, 0 = DPP reductions, 1 = LDS atomics
+	UGRT_OPT_DDA_CULL_WORK,    // "dda_cull_work": window kernel: (triangles x rays) of a job from which its list is culled first
 	UGRT_OPT_COUNT
 };
 
@@ -119,8 +119,9 @@ struct ugrt_ctx {
 	DevBuf temp;                  // rocPRIM temporary storage
 	DevBuf scan_state;            // own scan: ticket + done counter (64 B), then one epoch-tagged state word per tile
 	u32 scan_epoch = 0;           // tag of the last scan's state words
-	DevBuf rs_state, rs_tmp[2];   // own radix sort: histograms + tickets + look-back words, ping-pong buffers
-	int rs_flip = 0;              // which of rs_state's two histogram blocks the next sort uses (the other one is cleared by it)
+	DevBuf rs_state, rs_tmp[2];   // own radix sort: per-site histogram rows + tickets, look-back words; ping-pong buffers
+	u32 rs_epoch = 0;             // tag of the last pass's look-back words
+	bool rs_dirty[8] = { false }; // per sort site: a producer was handed the histogram rows and its sort has not run yet
 	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
 	// gather ONE record per reference instead of 3 indices + 3 vertices
 	DevBuf trirec;

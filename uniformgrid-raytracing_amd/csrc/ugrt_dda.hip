@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_beam(DGrid g, const u32 *__
 int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
 			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
 			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
-			 bool counting, u32 RPW, u32 CULL_MIN, u32 BOXMODE, int blocks);
+			 bool counting, u32 RPW, u32 CULL_MIN, u32 CULL_WORK, int blocks);
 int ugrt_dda_sort_keys_launch(ugrt_ctx *ctx, const DGrid &g, const float *d_rays, const u32 *list, const u32 *dcount, u32 cap,
 			      u32 *keys);
 
@@ -768,7 +768,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		if ((rc = ugrt_dda_walk_launch(ctx, g, d_value_list, d_span, d_offset, (u32 *)ctx->ubitmap.p, d_vertlist, d_trilist, rec,
 					       d_rays, (const u32 *)list, (const u32 *)dcount, d_hit_t, d_hit_id,
 					       counting ? dc : (unsigned long long *)nullptr, counting, DDA_RPW, CULL_MIN,
-					       ctx->opt[UGRT_OPT_DDA_BOX] == 1 ? 1u : 0u, blocks)))
+					       ctx->opt[UGRT_OPT_DDA_CULL_WORK] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_WORK] : 320u, blocks)))
 			return rc;
 		if (counting) {
 			unsigned long long h[DS_END];

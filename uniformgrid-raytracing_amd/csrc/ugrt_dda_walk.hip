@@ -19,7 +19,7 @@
 //     (survivor, ray) PAIRS: a job with n <= 32 rays tests floor(64 / n) survivors per round, rays and survivors
 //     come from LDS, closest hits are merged per ray by ds_min_u64 on (t bits << 32 | list position) -- the strict
 //     `<` of the sequential loop in list order.  Lone rays are jobs of one ray (64 triangles per round).
-// Results are bit-identical to the other two kernels and to the oracle (tests/test_gpu_parity.py).
+// Results are bit-identical to the other two kernels (tests/test_gpu_parity.py checks all three against the CPU restatement).
 #include "ugrt_dda.h"
 
 #define WK_AHEAD 8    // steps planned per window
@@ -85,56 +85,6 @@ __global__ __launch_bounds__(256) void k_dda_sort_keys(DGrid g, const float *__r
 	keys[i] = (cell << 3) | oct;
 }
 
-// The bundle box of d_beam_box (ugrt_dda.h) with the thirteen wave reductions done by the LDS instead of the DPP
-// path: the rays of the job issue ds_min / ds_max on the order-preserving integer images of their values (13
-// instructions whatever the number of rays; the DPP form is 13 dependent chains of seven steps each).  Same
-// minima and maxima, hence the same box.  s_box: 16 words.
-__device__ __forceinline__ BeamBox d_beam_box_lds(int *s_box, const float *o, const float *d, float tin, bool in, int lane)
-{
-	if (lane < 13)
-		s_box[lane] = lane < 6 ? 0x7FFFFFFF : (int)0x80000000;
-	__syncthreads();
-	if (in) {
-#pragma unroll
-		for (int k = 0; k < 3; k++) {
-			const int pk = d_ordered(o[k] + tin * d[k]), dk = d_ordered(d[k]);
-			atomicMin(&s_box[k], pk);
-			atomicMax(&s_box[6 + k], pk);
-			atomicMin(&s_box[3 + k], dk);
-			atomicMax(&s_box[9 + k], dk);
-		}
-		atomicMax(&s_box[12], d_ordered(tin));
-	}
-	__syncthreads();
-	BeamBox bx;
-	float on2 = 0.0f, dm2 = 0.0f;
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		float lo = d_unordered(s_box[k]), hi = d_unordered(s_box[6 + k]);
-		bx.oc[k] = 0.5f * (lo + hi);
-		bx.orad[k] = 0.5f * (hi - lo) * 1.0001f + 7.63e-6f * fmaxf(fabsf(lo), fabsf(hi)) + 1e-6f;
-		on2 += bx.orad[k] * bx.orad[k];
-		lo = d_unordered(s_box[3 + k]);
-		hi = d_unordered(s_box[9 + k]);
-		bx.dc[k] = 0.5f * (lo + hi);
-		bx.dr[k] = 0.5f * (hi - lo) * 1.0001f + 1e-6f;
-		const float da = fabsf(bx.dc[k]) + bx.dr[k];
-		dm2 += da * da;
-	}
-	const float tmax = d_unordered(s_box[12]);
-	const float on = __builtin_sqrtf(on2) * 1.0001f, dmax = __builtin_sqrtf(dm2) * 1.0001f;
-	bx.reach = (tmax * dmax + on) * 1.001f;
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		bx.oc[k] = d_uniform(bx.oc[k]);
-		bx.dc[k] = d_uniform(bx.dc[k]);
-		bx.dr[k] = d_uniform(bx.dr[k]);
-		bx.orad[k] = d_uniform(bx.orad[k]);
-	}
-	bx.reach = d_uniform(bx.reach);
-	return bx;
-}
-
 #define WK_STAMP(PH)                                                          \
 	do {                                                                  \
 		if (COUNT) {                                                  \
@@ -152,7 +102,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 							const float *__restrict__ rays, const u32 *__restrict__ list,
 							const u32 *__restrict__ count_p, float *__restrict__ hit_t,
 							int *__restrict__ hit_id, unsigned long long *__restrict__ counters,
-							u32 RPW, u32 CULL_MIN, u32 BOXMODE, u32 *__restrict__ ticket)
+							u32 RPW, u32 CULL_MIN, u32 CULL_WORK, u32 *__restrict__ ticket)
 {
 	__shared__ u32 s_cell[WK_AHEAD][64];    // cell of (step, ray); written for occupied cells only
 	__shared__ float s_tnext[WK_AHEAD][64]; // exit parameter of (step, ray); the entry of step q is the exit of q - 1
@@ -162,7 +112,6 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 	__shared__ u32 s_jcell[WK_JOBCAP], s_jbase[WK_JOBCAP], s_jlen[WK_JOBCAP];
 	__shared__ unsigned char s_jq[WK_JOBCAP];
 	__shared__ unsigned char s_rank[64]; // k-th ray of the running job
-	__shared__ int s_box[16];            // bundle box of the running job (ordered-integer minima and maxima)
 	const int lane = threadIdx.x;
 	const u32 count = *count_p;
 	for (u32 grp = blockIdx.x; (unsigned long long)grp * RPW < count;) {
@@ -419,13 +368,16 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 							if (in)
 								n_tests += S;
 						}
-						const bool use_cull = S >= CULL_MIN;
+						// Cull first?  The bundle box and the cull of a batch cost about as much as three exact rounds, an exact
+						// round tests up to 64 (survivor, ray) pairs, and the cull removes about 60 % of a list: it pays from a few
+						// hundred (triangle, ray) pairs on.
+						const bool use_cull = S >= CULL_MIN && S * n >= CULL_WORK;
 						BeamBox bx;
 						if (use_cull) { // the bundle box is formed from the rays' own lanes
 							const float4 a = *reinterpret_cast<const float4 *>(&s_ray[lane * 8]);
 							const float2 b = *reinterpret_cast<const float2 *>(&s_ray[lane * 8 + 4]);
 							const float o[3] = { a.x, a.y, a.z }, d[3] = { a.w, b.x, b.y };
-							bx = BOXMODE ? d_beam_box_lds(s_box, o, d, tin, in, lane) : d_beam_box(o, d, tin, in);
+							bx = d_beam_box(o, d, tin, in);
 						}
 						WK_STAMP(3);
 						// lanes as (survivor, ray) pairs: pair slot `lane` = survivor lane / n, ray number lane % n of the job
@@ -591,7 +543,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
 			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
 			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
-			 bool counting, u32 RPW, u32 CULL_MIN, u32 BOXMODE, int blocks)
+			 bool counting, u32 RPW, u32 CULL_MIN, u32 CULL_WORK, int blocks)
 {
 	const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
 	const u32 bblocks = (ncell + 255u) / 256u;
@@ -601,7 +553,7 @@ int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list,
 #define WK_LAUNCH(CNTV, RECV)                                                                                          \
 	hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
 			   d_offset, (const u32 *)bitmap, d_vertlist, d_trilist, rec, d_rays, list, dcount, d_hit_t, d_hit_id, \
-			   counters, RPW, CULL_MIN, BOXMODE, ticket)
+			   counters, RPW, CULL_MIN, CULL_WORK, ticket)
 	if (counting) {
 		if (rec)
 			WK_LAUNCH(true, true);

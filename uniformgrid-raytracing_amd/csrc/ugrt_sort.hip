@@ -4,9 +4,11 @@
 // seven sorts of a frame (three grid builds, the ray sort, the shadow tracer's three private sorts).
 // They are small (0.2-3 M pairs on 8-32 key bits), so the fixed cost per pass matters as much as the
 // bandwidth: a library onesweep spends one histogram kernel, one digit-scan kernel and 1 + 2*passes
-// buffer fills per sort besides the passes.  Here: ONE fill (all counters of all passes), ONE histogram
-// kernel (all digits in one read of the keys) and one kernel per pass, which scans the 256 digit totals
-// itself.
+// buffer fills per sort besides the passes.  Here a sort is its passes and nothing else:
+//   - the digit histograms of all passes are accumulated by the kernel that writes the keys
+//     (ugrt_rs_hist.h; a histogram kernel remains for keys that come from outside);
+//   - the state needs no clearing: the look-back words carry the EPOCH of their pass beside the count,
+//     and the last workgroup of a pass to finish zeroes that pass's histogram row, ticket and counter.
 //
 // Pass kernel, one workgroup of 512 threads per tile of 8192 pairs:
 //   - tiles are taken in launch order from an atomic ticket, so a tile only ever waits for tiles that
@@ -14,47 +16,35 @@
 //     the predecessor's inclusive prefix) would propagate through the tiles one round trip at a time.
 //     Instead the digit counts are combined in two levels without a chain: every tile publishes its
 //     counts, the last tile of each chunk of 16 publishes the chunk's sum, and a tile's offset is the
-//     sum of the chunk sums before its chunk + the counts of the tiles before it inside the chunk
-//     (<= 15 + tiles/16 independent loads per digit, about three round trips in all);
+//     sum of the chunk sums before its chunk + the counts of the tiles before it inside the chunk.
+//     The counts of a chunk's 16 tiles for one digit lie side by side (128 B), the chunk sums of a digit
+//     too: the thread of a digit reads one or two cache lines per level through one base address
+//     (tile-major rows cost a line and an address register pair per tile: 29 spilled registers);
 //   - ranking is wave-synchronous: the 64 lanes of a wave find their equal-digit group with 8 ballots,
 //     the group's first lane bumps the wave's digit counter in LDS; items are visited in memory order,
 //     which makes the sort stable;
 //   - the tile is put in digit order in LDS and written out in runs, so the scatter is coalesced.
-#include "ugrt_ctx.h"
+#include "ugrt_rs_hist.h"
 
 #define RS_THREADS 512
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_ITEMS 16
 #define RS_TILE (RS_THREADS * RS_ITEMS)
-#define RS_BINS 256
-#define RS_MAXPASS 4
 #define RS_CHUNK 16 // tiles per chunk of the two-level offset computation
 
-#define RS_FLAG 0x80000000u // set in a published count (counts are < 2^31)
-#define RS_VALUE 0x7FFFFFFFu
+// state of one site (u32 words): histogram rows, then per pass {ticket, finished workgroups}
+#define RS_SITE_WORDS (RS_MAXPASS * RS_BINS + 2 * RS_MAXPASS + 56)
 
-// digit histograms of all passes in one read of the keys
+typedef unsigned long long u64w; // look-back word: epoch << 32 | count
+
+// digit histograms of all passes in one read of the keys: for keys no kernel of this library wrote
 // (n_dev: the number of pairs when only the device knows it; n is then the capacity the launch was sized for)
-// It also clears what the kernels after it expect to be zero, so that a sort needs no fill: the look-back words of
-// this sort's passes (`look`) and the histogram + ticket block of the NEXT sort (`next_head`; the two blocks of the
-// state alternate from sort to sort, both on the context's stream).
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, int passes, u32 end_bit,
-							 u32 *__restrict__ hist, const u32 *__restrict__ n_dev,
-							 u32 *__restrict__ next_head, u32 head_words, u32 *__restrict__ look,
-							 u32 look_words)
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, RsHist h, const u32 *__restrict__ n_dev)
 {
-	for (u32 i = blockIdx.x * RS_THREADS + threadIdx.x; i < head_words + look_words; i += gridDim.x * RS_THREADS) {
-		if (i < head_words)
-			next_head[i] = 0u;
-		else
-			look[i - head_words] = 0u;
-	}
 	if (n_dev)
 		n = *n_dev < n ? *n_dev : n;
-	__shared__ u32 s_h[RS_MAXPASS][RS_BINS];
-	if (threadIdx.x < RS_BINS)
-		for (int p = 0; p < passes; p++)
-			s_h[p][threadIdx.x] = 0;
+	__shared__ u32 s_h[RS_MAXPASS * RS_BINS];
+	d_rs_hist_zero(s_h, h);
 	__syncthreads();
 	// few workgroups: every one ends with up to 256 * passes global adds on the same 256 * passes words
 	const u32 stride = gridDim.x * RS_THREADS;
@@ -64,32 +54,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
 		for (u32 u = 0; u < 4; u++)
 			k4[u] = i0 + u * stride < n ? keys[i0 + u * stride] : 0u;
 #pragma unroll
-		for (u32 u = 0; u < 4; u++) {
-			const bool ok = i0 + u * stride < n;
-			const unsigned long long act = __ballot(ok);
-			if (!ok)
-				continue;
-			for (int p = 0; p < passes; p++) {
-				const u32 bits = end_bit - 8u * (u32)p < 8u ? end_bit - 8u * (u32)p : 8u;
-				const u32 d = (k4[u] >> (8 * p)) & ((1u << bits) - 1u);
-				// neighbouring keys mostly share their upper digits (cell ids in fill order): one add per wave then
-				const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
-				if (__ballot(d == d0) == act) {
-					if ((threadIdx.x & 63u) == (u32)__builtin_ctzll(act))
-						atomicAdd(&s_h[p][d0], (u32)__popcll(act));
-				} else {
-					atomicAdd(&s_h[p][d], 1u);
-				}
-			}
-		}
+		for (u32 u = 0; u < 4; u++)
+			d_rs_hist_add(s_h, h, k4[u], i0 + u * stride < n);
 	}
 	__syncthreads();
-	if (threadIdx.x < RS_BINS)
-		for (int p = 0; p < passes; p++) {
-			const u32 c = s_h[p][threadIdx.x];
-			if (c)
-				atomicAdd(&hist[p * RS_BINS + threadIdx.x], c);
-		}
+	d_rs_hist_flush(s_h, h);
 }
 
 // exclusive scan of one value per thread over the threads of the block (s_part: RS_WAVES words of LDS)
@@ -114,10 +83,36 @@ __device__ __forceinline__ u32 d_block_excl_scan(u32 v, u32 *s_part)
 	return base + incl - v;
 }
 
+// sum of the `count` consecutive look-back words at `row`, each awaited until it carries this pass's epoch; eight
+// loads in flight at a time through one base address
+__device__ __forceinline__ u32 d_rs_wait_sum(const u64w *row, u32 count, u32 epoch)
+{
+	const u64w tag = (u64w)epoch << 32;
+	u32 sum = 0;
+	for (u32 c0 = 0; c0 < count; c0 += 8u) {
+		u64w s[8];
+		bool again;
+		do {
+			again = false;
+#pragma unroll
+			for (u32 w = 0; w < 8u; w++)
+				s[w] = c0 + w < count ? __hip_atomic_load(row + c0 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+#pragma unroll
+			for (u32 w = 0; w < 8u; w++)
+				again = again || (u32)(s[w] >> 32) != epoch;
+		} while (again);
+#pragma unroll
+		for (u32 w = 0; w < 8u; w++)
+			sum += (u32)s[w];
+	}
+	return sum;
+}
+
+// look:  [chunk][digit][RS_CHUNK] tile counts;  look2: [digit][chunk_cap] chunk sums;  ctl: {ticket, finished}
 __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
 							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
-							 u32 dmask, const u32 *__restrict__ hist, u32 *look, u32 *look2,
-							 u32 *ticket, const u32 *__restrict__ n_dev)
+							 u32 dmask, u32 *hist, u64w *look, u64w *look2, u32 chunk_cap, u32 *ctl,
+							 u32 epoch, const u32 *__restrict__ n_dev, u32 rows_to_clear)
 {
 	if (n_dev)
 		n = *n_dev < n ? *n_dev : n;
@@ -126,17 +121,17 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 	__shared__ u32 s_lstart[RS_BINS]; // first slot of the digit inside the sorted tile
 	__shared__ u32 s_base[RS_BINS];   // global position of slot j of digit d = s_base[d] + j
 	__shared__ u32 s_part[RS_WAVES];
-	__shared__ u32 s_tile;
+	__shared__ u32 s_tile, s_last;
 	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
 	if (t == 0)
-		s_tile = atomicAdd(ticket, 1u);
+		s_tile = atomicAdd(&ctl[0], 1u);
 	for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS)
 		(&s_cnt[0][0])[i] = 0;
 	__syncthreads();
 	const u32 tile = s_tile;
 	const u32 base = tile * RS_TILE;
-	if (base >= n)
-		return; // a launch sized by the capacity: this tile holds nothing, and no tile waits for a later one
+	// (a launch sized by the capacity: a tile beyond the pairs holds nothing, and no tile waits for a later one)
+	if (base < n) {
 	u32 k[RS_ITEMS], r[RS_ITEMS];
 #pragma unroll
 	for (int i = 0; i < RS_ITEMS; i++) {
@@ -183,54 +178,20 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 	const u32 lstart = d_block_excl_scan(total, s_part);
 	const u32 gdigit = d_block_excl_scan(digit ? hist[t] : 0u, s_part);
 	if (digit) {
-	// digit t: offset of this tile = counts of all tiles before it, combined in two levels (no chain)
-	const u32 chunk = tile / RS_CHUNK, first = chunk * RS_CHUNK;
-	__hip_atomic_store(look + (size_t)tile * RS_BINS + t, total | RS_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	u32 excl = 0;
-	{
+		// digit t: offset of this tile = counts of all tiles before it, combined in two levels (no chain)
+		const u32 chunk = tile / RS_CHUNK, nb = tile - chunk * RS_CHUNK;
+		const u64w tag = (u64w)epoch << 32;
+		u64w *row = look + ((size_t)chunk * RS_BINS + t) * RS_CHUNK; // this digit's counts of the chunk's 16 tiles
+		__hip_atomic_store(row + nb, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		// the tiles before this one inside its chunk (they hold lower tickets: they run or have finished)
-		u32 s[RS_CHUNK - 1];
-		const u32 nb = tile - first;
-		bool again;
-		do {
-			again = false;
-#pragma unroll
-			for (u32 w = 0; w < RS_CHUNK - 1; w++)
-				s[w] = w < nb ? __hip_atomic_load(look + (size_t)(first + w) * RS_BINS + t, __ATOMIC_RELAXED,
-								  __HIP_MEMORY_SCOPE_AGENT)
-					      : RS_FLAG;
-#pragma unroll
-			for (u32 w = 0; w < RS_CHUNK - 1; w++)
-				again = again || (s[w] & RS_FLAG) == 0u;
-		} while (again);
-#pragma unroll
-		for (u32 w = 0; w < RS_CHUNK - 1; w++)
-			excl += s[w] & RS_VALUE;
-	}
-	if (tile - first == RS_CHUNK - 1u) // the chunk is complete with this tile: publish its sum
-		__hip_atomic_store(look2 + (size_t)chunk * RS_BINS + t, (excl + total) | RS_FLAG, __ATOMIC_RELAXED,
-				   __HIP_MEMORY_SCOPE_AGENT);
-	// the chunks before this one (their last tiles hold lower tickets)
-	for (u32 c0 = 0; c0 < chunk; c0 += RS_CHUNK) {
-		u32 s[RS_CHUNK];
-		bool again;
-		do {
-			again = false;
-#pragma unroll
-			for (u32 w = 0; w < RS_CHUNK; w++)
-				s[w] = c0 + w < chunk ? __hip_atomic_load(look2 + (size_t)(c0 + w) * RS_BINS + t, __ATOMIC_RELAXED,
-									  __HIP_MEMORY_SCOPE_AGENT)
-						      : RS_FLAG;
-#pragma unroll
-			for (u32 w = 0; w < RS_CHUNK; w++)
-				again = again || (s[w] & RS_FLAG) == 0u;
-		} while (again);
-#pragma unroll
-		for (u32 w = 0; w < RS_CHUNK; w++)
-			excl += s[w] & RS_VALUE;
-	}
-	s_lstart[t] = lstart;
-	s_base[t] = gdigit + excl - lstart;
+		u32 excl = d_rs_wait_sum(row, nb, epoch);
+		u64w *row2 = look2 + (size_t)t * chunk_cap; // this digit's chunk sums
+		if (nb == RS_CHUNK - 1u) // the chunk is complete with this tile: publish its sum
+			__hip_atomic_store(row2 + chunk, tag | (u64w)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// the chunks before this one (their last tiles hold lower tickets)
+		excl += d_rs_wait_sum(row2, chunk, epoch);
+		s_lstart[t] = lstart;
+		s_base[t] = gdigit + excl - lstart;
 	} // digit
 	__syncthreads();
 	// tile in digit order in LDS (the values are fetched only now: they would occupy registers all the way)
@@ -258,13 +219,85 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 		kout[pos] = key;
 		vout[pos] = s_vals[j];
 	}
+	} // base < n
+	// the last workgroup to finish leaves this pass's histogram row, ticket and counter at zero for the next sort
+	// at this site (every workgroup has read its row by now: a workgroup counts itself in after its own reads)
+	__syncthreads();
+	if (t == 0)
+		s_last = atomicAdd(&ctl[1], 1u) == gridDim.x - 1u ? 1u : 0u;
+	__syncthreads();
+	if (s_last) {
+		// (the last pass also clears the rows above its own: a producer that did not know the key width has counted
+		// zeros into them)
+		for (u32 i = t; i < rows_to_clear * RS_BINS; i += RS_THREADS)
+			hist[i] = 0u;
+		if (t == 0) {
+			ctl[0] = 0u;
+			ctl[1] = 0u;
+		}
+	}
 }
 
-// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
-int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
-			const u32 *n_dev)
+static int rs_state(ugrt_ctx *ctx, u32 tiles)
 {
-	if (n == 0)
+	// [RS_SITES] site blocks, then the look-back words of the running pass: tile counts, chunk sums
+	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
+	const size_t look_words64 = (size_t)chunks * RS_BINS * RS_CHUNK + (size_t)RS_BINS * chunks;
+	const size_t bytes = (size_t)RS_SITES * RS_SITE_WORDS * 4 + look_words64 * 8;
+	const void *before = ctx->rs_state.p;
+	if (bytes <= ctx->rs_state.cap)
+		return UGRT_OK;
+	// growing: the site blocks of a sort in preparation (histogram rows a producer has added to) must survive
+	DevBuf old = ctx->rs_state;
+	ctx->rs_state = DevBuf();
+	int rc = ugrt_buf_reserve(ctx, ctx->rs_state, bytes);
+	if (rc) {
+		ctx->rs_state = old;
+		return rc;
+	}
+	UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, ctx->rs_state.cap, ctx->stream));
+	if (before) {
+		UGRT_HIP(hipMemcpyAsync(ctx->rs_state.p, before, (size_t)RS_SITES * RS_SITE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
+		UGRT_HIP(hipStreamSynchronize(ctx->stream));
+		(void)hipFree(old.p);
+	}
+	ctx->rs_epoch = 0;
+	return UGRT_OK;
+}
+
+int ugrt_sort_hist_arg(ugrt_ctx *ctx, int site, int end_bit, RsHist *out)
+{
+	int rc = rs_state(ctx, 1);
+	if (rc)
+		return rc;
+	if (end_bit < 1)
+		end_bit = 1;
+	if (end_bit > 32)
+		end_bit = 32;
+	static_assert(RS_SITES <= 8, "ugrt_ctx::rs_dirty");
+	if (ctx->rs_dirty[site] && (rc = ugrt_sort_hist_reset(ctx, site))) // a producer ran and its sort never did (an error between them)
+		return rc;
+	ctx->rs_dirty[site] = true;
+	out->hist = (u32 *)ctx->rs_state.p + (size_t)site * RS_SITE_WORDS;
+	out->end_bit = (u32)end_bit;
+	out->passes = (end_bit + 7) / 8;
+	return UGRT_OK;
+}
+
+// forget what a producer has added to a site's rows (its sort will not run: the producer is repeated)
+int ugrt_sort_hist_reset(ugrt_ctx *ctx, int site)
+{
+	if (!ctx->rs_state.p)
+		return UGRT_OK;
+	UGRT_HIP(hipMemsetAsync((u32 *)ctx->rs_state.p + (size_t)site * RS_SITE_WORDS, 0, (size_t)RS_MAXPASS * RS_BINS * 4, ctx->stream));
+	ctx->rs_dirty[site] = false;
+	return UGRT_OK;
+}
+
+int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
+			 int end_bit, const u32 *n_dev)
+{
+	if (n == 0 && !prehist)
 		return UGRT_OK;
 	if (n > ((size_t)1 << 30))
 		return ugrt_fail(UGRT_EINVAL, "sort: %zu pairs exceed 2^30", n);
@@ -273,46 +306,55 @@ int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin
 	if (end_bit > 32)
 		end_bit = 32;
 	const int passes = (end_bit + 7) / 8;
-	const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
+	const u32 tiles = n ? (u32)((n + RS_TILE - 1) / RS_TILE) : 1u; // (n == 0 with histogram rows to clear: one idle tile)
 	hipStream_t st = ctx->stream;
 	int rc;
-	// state: two blocks of {[RS_MAXPASS][256] histograms, [256] tickets} that alternate from sort to sort, then per
-	// pass [tiles][256] tile counts and [chunks][256] chunk sums
-	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
-	const size_t per_pass = (size_t)(tiles + chunks) * RS_BINS;
-	const size_t head = (size_t)RS_MAXPASS * RS_BINS + RS_BINS;
-	const size_t words = 2 * head + (size_t)passes * per_pass;
-	const void *before = ctx->rs_state.p;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->rs_state, words * 4)))
+	if ((rc = rs_state(ctx, tiles)))
 		return rc;
 	if (passes > 1) {
-		if ((rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[0], n * 4)) || (rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[1], n * 4)))
+		if ((rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[0], (n ? n : 1) * 4)) || (rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[1], (n ? n : 1) * 4)))
 			return rc;
 	}
-	if (ctx->rs_state.p != before) { // a new allocation: nothing has cleared the first block yet
-		UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, 2 * head * 4, st));
-		ctx->rs_flip = 0;
+	if (prehist)
+		ctx->rs_dirty[site] = false;
+	u32 *sitep = (u32 *)ctx->rs_state.p + (size_t)site * RS_SITE_WORDS;
+	u32 *hist = sitep, *ctl = sitep + RS_MAXPASS * RS_BINS;
+	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
+	u64w *look = (u64w *)((u32 *)ctx->rs_state.p + (size_t)RS_SITES * RS_SITE_WORDS);
+	u64w *look2 = look + (size_t)chunks * RS_BINS * RS_CHUNK;
+	if (!prehist) {
+		RsHist h;
+		h.hist = hist;
+		h.end_bit = (u32)end_bit;
+		h.passes = passes;
+		u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
+		hblocks = hblocks > 256u ? 256u : (hblocks ? hblocks : 1u);
+		hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, h, n_dev);
+		UGRT_HIP(hipGetLastError());
 	}
-	u32 *hist = (u32 *)ctx->rs_state.p + (size_t)ctx->rs_flip * head, *ticket = hist + (size_t)RS_MAXPASS * RS_BINS;
-	u32 *next_head = (u32 *)ctx->rs_state.p + (size_t)(ctx->rs_flip ^ 1) * head, *look = (u32 *)ctx->rs_state.p + 2 * head;
-	ctx->rs_flip ^= 1;
-	u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
-	hblocks = hblocks > 256u ? 256u : hblocks;
-	hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, passes, (u32)end_bit, hist, n_dev,
-			   next_head, (u32)head, look, (u32)((size_t)passes * per_pass));
-	UGRT_HIP(hipGetLastError());
 	const u32 *ki = kin, *vi = vin;
 	for (int p = 0; p < passes; p++) {
 		// the buffers alternate so that the last pass writes the caller's output
 		const bool to_out = ((passes - 1 - p) & 1) == 0;
 		u32 *ko = to_out ? kout : (u32 *)ctx->rs_tmp[0].p, *vo = to_out ? vout : (u32 *)ctx->rs_tmp[1].p;
 		const u32 bits = (u32)(end_bit - 8 * p) < 8u ? (u32)(end_bit - 8 * p) : 8u;
+		if (++ctx->rs_epoch == 0u) { // (2^32 passes later: old tags could be taken for new ones)
+			UGRT_HIP(hipMemsetAsync(look, 0, ctx->rs_state.cap - (size_t)RS_SITES * RS_SITE_WORDS * 4, st));
+			ctx->rs_epoch = 1;
+		}
 		hipLaunchKernelGGL(k_rs_pass, dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),
-				   (1u << bits) - 1u, (const u32 *)(hist + (size_t)p * RS_BINS),
-				   look + (size_t)p * per_pass, look + (size_t)p * per_pass + (size_t)tiles * RS_BINS, ticket + p, n_dev);
+				   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,
+				   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u);
 		UGRT_HIP(hipGetLastError());
 		ki = ko;
 		vi = vo;
 	}
 	return UGRT_OK;
+}
+
+// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
+int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
+			const u32 *n_dev)
+{
+	return ugrt_sort_pairs_site(ctx, RS_SITE_MISC, false, kin, kout, vin, vout, n, end_bit, n_dev);
 }

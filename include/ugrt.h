@@ -223,7 +223,7 @@ int ugrt_grid_get_info(ugrt_ctx *ctx, int which, ugrt_grid_info *out);
 int ugrt_grid_get_slabs(ugrt_ctx *ctx, int which, ugrt_slab_info *out);
 /* Sharded build of the light grid and the uniform grid across the GPUs of a node (not in the reference, which
  * has one GPU).  Each rank restricts its builds to a window [begin, end) of the triangle list
- * (end = 0: to the last triangle; 0, 0 restores the full build), the ranks exchange the arrays of their shards
+ * (end < 0: to the last triangle, so 0, -1 restores the full build; begin == end: an empty shard), the ranks exchange the arrays of their shards
  * (ugrt_grid_get_info: keys, values, span; total_refs entries) and every rank merges them: part r must hold the
  * window of rank r, windows ascending with r and disjoint.  The merged arrays become the context's grid and are
  * element for element those of a full build.  The parts are the caller's buffers, not the context's arrays. */

@@ -9,8 +9,17 @@
 // side stream beside the camera pass; the builds do not wait for the device: option async_build), `reflect 1` adds
 // the bounce (uniform grid + 3D-DDA).
 //
+// `ranks N` cuts the frame into N bands of tile rows, one PROCESS per GPU (started here, before anything touches a
+// GPU): every rank renders its band with the same display(), and the RGB bands are gathered on rank 0 by RCCL
+// (ncclSend / ncclRecv inside one group: point-to-point fan-in, each peer on its own xGMI link) - the one
+// collective of a frame.  `ranks 1` runs the same gather on a communicator of one.
+//
 //   display_main PARAMS OUT.ppm        PARAMS: lines "key v0 v1 ..." (see read_params)
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstring>
@@ -46,7 +55,7 @@ int frame_cnt = 0;
 struct Params {
 	char obj[512], mat[512];
 	float cam[11], light[11]; // eye, look, up, near, far
-	int streams, reflect, frames, animate_size, animate_offset;
+	int streams, reflect, frames, animate_size, animate_offset, ranks;
 	unsigned flags;
 } P;
 
@@ -58,7 +67,7 @@ static void read_params(const char *path)
 		exit(1);
 	}
 	char key[64];
-	P.streams = 1, P.frames = 1;
+	P.streams = 1, P.frames = 1, P.ranks = 0;
 	while (fscanf(fp, "%63s", key) == 1) {
 		if (!strcmp(key, "obj"))
 			(void)!fscanf(fp, "%511s", P.obj);
@@ -80,6 +89,8 @@ static void read_params(const char *path)
 			(void)!fscanf(fp, "%d", &P.reflect);
 		else if (!strcmp(key, "frames"))
 			(void)!fscanf(fp, "%d", &P.frames);
+		else if (!strcmp(key, "ranks"))
+			(void)!fscanf(fp, "%d", &P.ranks);
 		else if (!strcmp(key, "flags"))
 			(void)!fscanf(fp, "%u", &P.flags);
 		else {
@@ -224,6 +235,28 @@ void display() // main.cu:59-302
 	shader->add_shadows(d_image, dData->d_is_shadowed); // main.cu:223
 }
 
+#define NCCL_CHECK(call)                                                              \
+	do {                                                                          \
+		ncclResult_t r_ = (call);                                             \
+		if (r_ != ncclSuccess) {                                              \
+			fprintf(stderr, "%s: %s\n", #call, ncclGetErrorString(r_)); \
+			exit(-1);                                                     \
+		}                                                                     \
+	} while (0)
+
+// what the ranks share before they have a communicator: rank 0's RCCL id
+struct Rendezvous {
+	ncclUniqueId id;
+	volatile int ready;
+};
+
+// tile rows [begin, end) of `rank`: sizes differ by at most one row (the rule of the Python harness: parallel.band_rows)
+static void band_rows(int rank, int ranks, int nby, int *begin, int *end)
+{
+	*begin = (int)((long long)rank * nby / ranks);
+	*end = (int)((long long)(rank + 1) * nby / ranks);
+}
+
 int main(int argc, char **argv)
 {
 	if (argc != 3) {
@@ -232,13 +265,60 @@ int main(int argc, char **argv)
 	}
 	read_params(argv[1]);
 	const size_t N = (size_t)g_width * g_height;
-	HIP_CHECK(hipSetDevice(0));
+	// one process per GPU: the children are started BEFORE any HIP or RCCL call of this process
+	const int ranks = P.ranks > 0 ? P.ranks : 1;
+	int rank = 0;
+	Rendezvous *rv = nullptr;
+	std::vector<pid_t> children;
+	if (P.ranks > 0) {
+		rv = (Rendezvous *)mmap(nullptr, sizeof(Rendezvous), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+		if (rv == MAP_FAILED) {
+			perror("mmap");
+			return 1;
+		}
+		rv->ready = 0;
+		for (int r = 1; r < ranks; r++) {
+			const pid_t pid = fork();
+			if (pid < 0) {
+				perror("fork");
+				return 1;
+			}
+			if (pid == 0) {
+				rank = r;
+				children.clear();
+				break;
+			}
+			children.push_back(pid);
+		}
+	}
+	int row_begin = 0, row_end = g_height / 8;
+	band_rows(rank, ranks, g_height / 8, &row_begin, &row_end);
+	HIP_CHECK(hipSetDevice(rank));
 	HIP_CHECK(hipStreamCreate(&g_main));
-	init_ugrt(g_width, g_height, P.flags);
+	ncclComm_t comm = nullptr;
+	if (P.ranks > 0) {
+		if (rank == 0) {
+			NCCL_CHECK(ncclGetUniqueId(&rv->id));
+			__sync_synchronize();
+			rv->ready = 1;
+		} else {
+			while (!rv->ready)
+				usleep(1000);
+			__sync_synchronize();
+		}
+		ncclUniqueId id = rv->id;
+		NCCL_CHECK(ncclCommInitRank(&comm, ranks, id, rank));
+	}
+	if (P.ranks == 0) {
+		init_ugrt(g_width, g_height, P.flags);
+	} else { // (init_ugrt of the shim, with this rank's band of tile rows and device)
+		ugrt_config cfg = { g_width, g_height, 8, 1, 128, 128, row_begin, row_end, P.flags, { 128, 128, 64 } };
+		UGRT_CHECK(ugrt_ctx_create(&g_ctx, rank, &cfg));
+	}
 	UGRT_CHECK(ugrt_ctx_set_stream(g_ctx, g_main));
 	if (P.streams == 2) {
-		ugrt_config cfg = { g_width, g_height, 8, 1, 128, 128, 0, g_height / 8, P.flags, { 128, 128, 64 } };
-		UGRT_CHECK(ugrt_ctx_create(&g_aux, 0, &cfg));
+		ugrt_config cfg = { g_width, g_height, 8, 1, 128, 128, row_begin, row_end, P.flags, { 128, 128, 64 } };
+		UGRT_CHECK(ugrt_ctx_create(&g_aux, rank, &cfg));
 		HIP_CHECK(hipStreamCreate(&g_side));
 		UGRT_CHECK(ugrt_ctx_set_stream(g_aux, g_side));
 		// builds that never wait for the device: this one host thread keeps both streams fed
@@ -280,13 +360,44 @@ int main(int argc, char **argv)
 		d_hit_t = dev_alloc<float>(N);
 		d_hit_id = dev_alloc<int>(N);
 	}
-	for (int f = 0; f < P.frames; f++)
+	unsigned char *d_gather = comm && rank == 0 ? dev_alloc<unsigned char>(3 * N) : nullptr;
+	for (int f = 0; f < P.frames; f++) {
 		display();
-	HIP_CHECK(hipMemcpyAsync(h_image, d_image, 3 * N, hipMemcpyDeviceToHost, g_main)); // main.cu:244
+		if (comm) {
+			// the frame's one collective: every rank's band of RGB rows to rank 0, in stream order behind the shading
+			NCCL_CHECK(ncclGroupStart());
+			const size_t off = (size_t)row_begin * 8 * g_width * 3, bytes = (size_t)(row_end - row_begin) * 8 * g_width * 3;
+			NCCL_CHECK(ncclSend(d_image + off, bytes, ncclUint8, 0, comm, g_main));
+			if (rank == 0)
+				for (int r = 0; r < ranks; r++) {
+					int b, e;
+					band_rows(r, ranks, g_height / 8, &b, &e);
+					NCCL_CHECK(ncclRecv(d_gather + (size_t)b * 8 * g_width * 3, (size_t)(e - b) * 8 * g_width * 3, ncclUint8, r, comm,
+							    g_main));
+				}
+			NCCL_CHECK(ncclGroupEnd());
+		}
+	}
+	if (rank == 0)
+		HIP_CHECK(hipMemcpyAsync(h_image, comm ? d_gather : d_image, 3 * N, hipMemcpyDeviceToHost, g_main)); // main.cu:244
 	UGRT_CHECK(ugrt_ctx_synchronize(g_ctx)); // (reports an asynchronous build that outgrew its estimate)
 	if (g_aux)
 		UGRT_CHECK(ugrt_ctx_synchronize(g_aux));
+	if (comm)
+		NCCL_CHECK(ncclCommDestroy(comm));
+	if (rank != 0)
+		return 0;
+	int bad = 0;
+	for (pid_t pid : children) {
+		int st = 0;
+		if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+			bad = 1;
+	}
+	if (bad) {
+		fprintf(stderr, "a rank failed\n");
+		return 1;
+	}
 	writePPM(argv[2]);
-	printf("frames %d streams %d chunks %zu\n", frame_cnt, P.streams, *dData->h_numCudaBlocks);
+	printf("frames %d streams %d ranks %d chunks %zu\n", frame_cnt, P.streams, ranks, *dData->h_numCudaBlocks);
 	return 0;
 }

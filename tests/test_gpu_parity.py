@@ -926,7 +926,7 @@ def test_sharded_grid_build_merge(ugrt, O, torch, name, nparts):
         ctx.synchronize()
         value, key, span, offset, gi = ctx.grid_arrays(which)
         got = [u32(x).copy() for x in (key, value, span, offset)] + [gi.total_refs, gi.cells_used]
-        ctx.set_face_window(0, 0)
+        ctx.set_face_window(0, -1)
         build()
         ctx.synchronize()
         value, key, span, offset, gi = ctx.grid_arrays(which)
@@ -1113,6 +1113,52 @@ def test_async_builds_equal_the_waiting_form(ugrt, O, torch):
     r4.display(setup_for(ugrt, big, "ref"), shadows=True, reflect=True)
     ctx3.synchronize()
     np.testing.assert_array_equal(r3.image.cpu().numpy(), r4.image.cpu().numpy())
+
+
+def test_async_build_growth_between_launch_size_and_buffer_capacity(ugrt, O, torch):
+    """A grid (and the shadow pass's pair list) that grows by about a third from one frame to the next: more than the
+    launches of an asynchronous build are sized for (the last need + 25 % + 64 K), less than the grow-only buffers
+    hold (1.5 x the first need).  The overflow check must be made against the LAUNCH size: every kernel of the build
+    runs one thread per reference of the launch, so a count between the two would leave references unfilled and
+    unsorted without any report.  Expected: UGRT_EOVERFLOW at the synchronisation, then a repaired frame; in every
+    case the buffers end up equal to a context that only ever built in the waiting form."""
+    a, b = ugrt.scenes.crash(scale=0.30), ugrt.scenes.crash(scale=0.405)
+    W, H, lg, ud = 320, 200, (64, 64), (32, 32, 16)
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS
+    ctx, ra = make(ugrt, a, W, H, lg, flags=flags, udims=ud)
+    ctx.set_option("async_build", 1)
+    for _ in range(3):
+        ra.display(setup_for(ugrt, a, "ref"), shadows=True, reflect=True)
+    ctx.synchronize()
+    refs_a = [ctx.grid_info(g).total_refs for g in (ugrt.GRID_PERSPECTIVE, ugrt.GRID_SPHERICAL, ugrt.GRID_UNIFORM)]
+    rb = ugrt.Renderer(ctx, b["verts"], b["faces"], b["matidx"], b["mat_list"], b["reflect"])
+    setup_b = setup_for(ugrt, b, "ref")
+    rb.display(setup_b, shadows=True, reflect=True)
+    raised = False
+    try:
+        ctx.synchronize()
+    except ugrt.UgrtError as e:
+        assert "asynchronous" in str(e)
+        raised = True
+    if raised:
+        rb.display(setup_b, shadows=True, reflect=True)  # waits, sizes exactly
+        ctx.synchronize()
+    wctx, wr = make(ugrt, b, W, H, lg, flags=flags, udims=ud)
+    wr.display(setup_b, shadows=True, reflect=True)
+    wctx.synchronize()
+    refs_b = [wctx.grid_info(g).total_refs for g in (ugrt.GRID_PERSPECTIVE, ugrt.GRID_SPHERICAL, ugrt.GRID_UNIFORM)]
+    # at least one grid lies in the window the old check missed; then the overflow must have been reported
+    in_window = [ra_ > 262144 and ra_ * 1.25 + 65536 < rb_ <= ra_ * 1.5 for ra_, rb_ in zip(refs_a, refs_b)]
+    assert any(in_window), (refs_a, refs_b)
+    assert raised, (refs_a, refs_b)
+    for which in (ugrt.GRID_PERSPECTIVE, ugrt.GRID_SPHERICAL, ugrt.GRID_UNIFORM):
+        x, y = ctx.grid_arrays(which), wctx.grid_arrays(which)
+        assert x[4].total_refs == y[4].total_refs
+        for p, q in zip(x[:4], y[:4]):
+            np.testing.assert_array_equal(u32(p), u32(q))
+    for n in ("t", "is_shadowed", "hit_id", "hit_t", "intersect_id", "image"):
+        np.testing.assert_array_equal(getattr(rb, n).cpu().numpy().view(np.uint8), getattr(wr, n).cpu().numpy().view(np.uint8),
+                                      err_msg=n)
 
 
 def test_async_build_meets_a_wide_triangle_it_was_not_built_for(ugrt, O, torch):

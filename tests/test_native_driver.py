@@ -39,10 +39,12 @@ def _read_ppm(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("streams,reflect,all_chunks", [(1, 0, 0), (2, 0, 1), (1, 1, 1), (2, 1, 1)])
-def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect, all_chunks):
+@pytest.mark.parametrize("streams,reflect,all_chunks,ranks", [(1, 0, 0, 0), (2, 0, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0),
+                                                              (1, 0, 0, 1), (2, 1, 1, 1)])
+def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect, all_chunks, ranks):
     """A C++ host (no Python, no torch in the process) loads the OBJ + material file, runs display() through the
-    shim classes and writes the PPM; the pixels are the oracle's frame."""
+    shim classes and writes the PPM; the pixels are the oracle's frame.  ranks = 1: the frame's RGB goes through the
+    RCCL band gather (ncclSend / ncclRecv on a communicator of one rank; N > 1 needs N GPUs)."""
     _build()
     d = str(tmp_path)
     s = ugrt.scenes.hall(d, scale=0.1) if not reflect else ugrt.scenes.crash(d, scale=0.02)
@@ -52,9 +54,10 @@ def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect
     params = os.path.join(d, "params.txt")
     with open(params, "w") as f:
         f.write("obj %s\nmat %s\nsize %d %d\ncamera %s\nlight_camera %s\nshading_light %s\nstreams %d\nreflect %d\n"
-                "frames 2\nflags %d\n" % (s["obj"], s["mat"], W, H, flat(cam), flat(lcam),
-                                        " ".join("%.9g" % v for v in s["shading_light"]), streams, reflect,
-                                        ugrt.FLAG_SHADOW_ALL_CHUNKS if all_chunks else 0))
+                "frames 2\nflags %d\n%s" % (s["obj"], s["mat"], W, H, flat(cam), flat(lcam),
+                                          " ".join("%.9g" % v for v in s["shading_light"]), streams, reflect,
+                                          ugrt.FLAG_SHADOW_ALL_CHUNKS if all_chunks else 0,
+                                          "ranks %d\n" % ranks if ranks else ""))
     out = os.path.join(d, "out.ppm")
     # the mtllib is opened relative to the cwd (obj_parser.cpp:417)
     p = subprocess.run([BIN, params, out], cwd=d, capture_output=True, text=True, timeout=300)

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restr
 
 // (grid-stride over the workgroup-sized parts: a bounded number of workgroups, each of which also accumulates the
 // digit histograms of the sort that follows -- ugrt_rs_hist.h -- and adds them to the sort's rows once at its end)
-#define FILL_MAX_BLOCKS 2048u
+#define FILL_MAX_BLOCKS 8192u
 __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
 							 const u32 *__restrict__ parts, u32 R, int ny, int nz,
 							 u32 *__restrict__ keys, u32 *__restrict__ vals,
@@ -714,9 +714,9 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, (const u32 *)rw);
 	// (the fill also accumulates the digit histograms of the sort of its keys)
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1;
+	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] != 0;
 	RsHist hs = { nullptr, 0u, 0 };
-	if (own_sort && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gi, bits_for(C), &hs)))
+	if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gi, bits_for(C), &hs)))
 		return rc;
 	hipLaunchKernelGGL(k_fill, dim3(nparts < FILL_MAX_BLOCKS ? nparts : FILL_MAX_BLOCKS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, (const Rng *)G.rng.p, (const u32 *)G.parts.p, 0u, ny, nz, k0, v0, (u32 *)G.span.p,
@@ -724,7 +724,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-	rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_GRID0 + gi, true, k0, k1, v0, v1, launchRn, bits_for(C), rw)
+	rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_GRID0 + gi, fused, k0, k1, v0, v1, launchRn, bits_for(C), rw)
 		      : ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, launchRn, bits_for(C), rw);
 	if (rc)
 		return rc;
@@ -840,8 +840,9 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p, (const u32 *)nullptr);
 		const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1 && Rn <= (1u << 30);
+		const bool fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] != 0;
 		RsHist hs = { nullptr, 0u, 0 };
-		if (own_sort && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gidx, bits_for(C), &hs)))
+		if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gidx, bits_for(C), &hs)))
 			return rc;
 		hipLaunchKernelGGL(k_fill, dim3(nparts < FILL_MAX_BLOCKS ? nparts : FILL_MAX_BLOCKS), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0,
@@ -849,7 +850,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-		rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_GRID0 + gidx, true, k0, k1, v0, v1, Rn, bits_for(C), nullptr)
+		rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_GRID0 + gidx, fused, k0, k1, v0, v1, Rn, bits_for(C), nullptr)
 			      : ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, Rn, bits_for(C));
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 		if (rc)
@@ -996,7 +997,7 @@ extern "C" int ugrt_grid_build_spherical(ugrt_ctx *ctx, const int *d_facelist, c
 	hipLaunchKernelGGL(k_count_sph, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, ctx->cam, d_facelist, d_vertlist, F, lx, ly, xM, yM, (Rng *)G.rng.p,
 			   (u32 *)G.sizes.p, (u32 *)G.wide.p, wide_counter(G, F),
-			   K > 1 ? (float *)G.projz.p : (float *)nullptr, ctx->face_lo, ctx->face_hi > 0 ? ctx->face_hi : F);
+			   K > 1 ? (float *)G.projz.p : (float *)nullptr, ctx->face_lo, ctx->face_hi >= 0 ? ctx->face_hi : F);
 	UGRT_HIP(hipGetLastError());
 	if (K > 1 && (rc = build_slabs(ctx, G, F, 9999.9f, -9999.9f))) // frustum_grid.h:386
 		return rc;
@@ -1036,7 +1037,7 @@ extern "C" int ugrt_grid_build_uniform(ugrt_ctx *ctx, const int *d_facelist, con
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_COUNT);
 	hipLaunchKernelGGL(k_count_uniform, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 			   ctx->stream, g, d_facelist, d_vertlist, F, (Rng *)G.rng.p, (u32 *)G.sizes.p, (u32 *)G.wide.p,
-			   wide_counter(G, F), ctx->face_lo, ctx->face_hi > 0 ? ctx->face_hi : F);
+			   wide_counter(G, F), ctx->face_lo, ctx->face_hi >= 0 ? ctx->face_hi : F);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_COUNT);
 	UGRT_HIP(hipGetLastError());
 	return build_common(ctx, G, F, (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2], g.dims[1], g.dims[2], 0,
@@ -1135,16 +1136,18 @@ extern "C" int ugrt_grid_merge_shards(ugrt_ctx *ctx, int which, int nparts, cons
 		return ugrt_fail(UGRT_ENOMEM, "grid_merge_shards: %llu references exceed the 32-bit lists", Rtot);
 	int rc;
 	// outputs: the context's grid arrays (the shard this context built is replaced; the parts are the caller's
-	// buffers and must not be these arrays)
+	// buffers and must not be these arrays: checked against the arrays as they are NOW, before a reserve below can
+	// free and re-allocate them)
+	for (int r = 0; r < nparts; r++)
+		for (int i = 0; i < 2; i++)
+			if (d_keys[r] == (const unsigned *)G.key[i].p || d_vals[r] == (const unsigned *)G.val[i].p ||
+			    d_span[r] == (const unsigned *)G.span.p)
+				return ugrt_fail(UGRT_EINVAL, "grid_merge_shards: part %d aliases the context's own grid arrays", r);
 	const size_t rb = (size_t)(Rtot ? Rtot : 1) * 4;
 	if ((rc = ugrt_buf_reserve(ctx, G.key[0], rb)) || (rc = ugrt_buf_reserve(ctx, G.val[0], rb)) ||
 	    (rc = ugrt_buf_reserve(ctx, G.span, (size_t)C * 8 + 16)) || (rc = ugrt_buf_reserve(ctx, G.offset, (size_t)C * 4)) ||
 	    (rc = ugrt_buf_reserve(ctx, G.parts, (size_t)(nparts + 1) * C * 4)))
 		return rc;
-	for (int r = 0; r < nparts; r++)
-		if (d_keys[r] == (const unsigned *)G.key[0].p || d_vals[r] == (const unsigned *)G.val[0].p ||
-		    d_span[r] == (const unsigned *)G.span.p)
-			return ugrt_fail(UGRT_EINVAL, "grid_merge_shards: part %d aliases the context's own grid arrays", r);
 	u32 *span = (u32 *)G.span.p, *used = span + 2 * (size_t)C, *before = (u32 *)G.parts.p, *start = before + (size_t)nparts * C;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
 	UGRT_HIP(hipMemsetAsync(used, 0, 4, st));
@@ -1170,15 +1173,18 @@ extern "C" int ugrt_grid_merge_shards(ugrt_ctx *ctx, int which, int nparts, cons
 	G.keys = (u32 *)G.key[0].p;
 	G.vals = (u32 *)G.val[0].p;
 	G.R = (u32)Rtot;
+	G.r_exact = true; // (the merged count, not the estimate of an asynchronous shard build)
+	G.async_pending = false;
 	return UGRT_OK;
 }
 
 extern "C" int ugrt_ctx_set_face_window(ugrt_ctx *ctx, int begin, int end)
 {
-	if (!ctx || begin < 0 || end < begin)
+	// end < 0: up to the last triangle ((0, -1) = every triangle); begin == end: an empty shard
+	if (!ctx || begin < 0 || (end >= 0 && end < begin))
 		return ugrt_fail(UGRT_EINVAL, "set_face_window: bad argument");
 	ctx->face_lo = begin;
-	ctx->face_hi = end; // 0 = up to the last triangle
+	ctx->face_hi = end;
 	return UGRT_OK;
 }
 

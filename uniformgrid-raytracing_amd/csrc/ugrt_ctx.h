@@ -37,6 +37,7 @@ enum {
 	UGRT_OPT_PRIMARY_WAVES,    // "primary_waves": single-wave workgroups of the primary tracer
 	UGRT_OPT_SHADOW_WAVES,     // "shadow_waves": the same for the two shadow kernels
 	UGRT_OPT_DDA_SORT,         // "dda_sort": 1 = the bounce's ray list is sorted by (entry cell, octant) instead of tile order
+	UGRT_OPT_SORT_FUSED,       // "sort_fused_hist": 0 = every sort reads its keys in a histogram kernel of its own (default: the kernels that write keys count their digits)
 	UGRT_OPT_DDA_CULL_WORK,    // "dda_cull_work": window kernel: (triangles x rays) of a job from which its list is culled first
 	UGRT_OPT_COUNT
 };
@@ -113,7 +114,7 @@ struct ugrt_ctx {
 	float tex_host[100]; // 5x5x4 direction table of the current camera (setDirectionTexture)
 	bool tex_dirty = false;
 	int nbx = 0, nby = 0; // screen grid
-	int face_lo = 0, face_hi = 0; // ugrt_ctx_set_face_window: triangles the light / uniform builds bin (hi 0 = all)
+	int face_lo = 0, face_hi = -1; // ugrt_ctx_set_face_window: triangles the light / uniform builds bin (hi < 0 = to the last)
 	int p0 = 0, npix = 0; // first pixel and pixel count of this context's band
 	Grid grid[3];
 	DevBuf temp;                  // rocPRIM temporary storage

@@ -730,7 +730,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	// which a lone ray's cell is tested by the whole wave, list length from which a shared cell is culled first
 	const int kernel = ctx->opt[UGRT_OPT_DDA_KERNEL] > 0 ? ctx->opt[UGRT_OPT_DDA_KERNEL] : 0; // 0 window, 1 per-ray, 2 beam
 	const bool beam = kernel != 1;
-	u32 DDA_RPW = ctx->opt[UGRT_OPT_DDA_RPW] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_RPW] : (beam ? 64u : 32u);
+	u32 DDA_RPW = ctx->opt[UGRT_OPT_DDA_RPW] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_RPW] : (kernel == 2 ? 64u : 32u);
 	const u32 DDA_COOP = ctx->opt[UGRT_OPT_DDA_COOP] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_COOP] : 8u;
 	const u32 CULL_MIN = ctx->opt[UGRT_OPT_DDA_CULL_MIN] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_MIN] : 8u;
 	if (DDA_RPW > 64u)

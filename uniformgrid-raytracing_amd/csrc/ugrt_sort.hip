@@ -17,9 +17,9 @@
 //     Instead the digit counts are combined in two levels without a chain: every tile publishes its
 //     counts, the last tile of each chunk of 16 publishes the chunk's sum, and a tile's offset is the
 //     sum of the chunk sums before its chunk + the counts of the tiles before it inside the chunk.
-//     The counts of a chunk's 16 tiles for one digit lie side by side (128 B), the chunk sums of a digit
-//     too: the thread of a digit reads one or two cache lines per level through one base address
-//     (tile-major rows cost a line and an address register pair per tile: 29 spilled registers);
+//     Rows are tile-major ([tile][digit]): the 256 digit threads of a workgroup read and write a row as one
+//     coalesced 2-KB access; the rows of a level are awaited eight at a time (uniform row bases, one per-thread
+//     offset: all fifteen at once cost an address register pair each and 29 spilled registers);
 //   - ranking is wave-synchronous: the 64 lanes of a wave find their equal-digit group with 8 ballots,
 //     the group's first lane bumps the wave's digit counter in LDS; items are visited in memory order,
 //     which makes the sort stable;
@@ -83,9 +83,9 @@ __device__ __forceinline__ u32 d_block_excl_scan(u32 v, u32 *s_part)
 	return base + incl - v;
 }
 
-// sum of the `count` consecutive look-back words at `row`, each awaited until it carries this pass's epoch; eight
-// loads in flight at a time through one base address
-__device__ __forceinline__ u32 d_rs_wait_sum(const u64w *row, u32 count, u32 epoch)
+// sum over `count` rows of the look-back word of this thread's digit (rows `stride` words apart, the first at `row`),
+// each awaited until it carries this pass's epoch; eight loads in flight at a time
+__device__ __forceinline__ u32 d_rs_wait_sum(const u64w *row, u32 count, u32 stride, u32 epoch)
 {
 	const u64w tag = (u64w)epoch << 32;
 	u32 sum = 0;
@@ -96,7 +96,8 @@ __device__ __forceinline__ u32 d_rs_wait_sum(const u64w *row, u32 count, u32 epo
 			again = false;
 #pragma unroll
 			for (u32 w = 0; w < 8u; w++)
-				s[w] = c0 + w < count ? __hip_atomic_load(row + c0 + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+				s[w] = c0 + w < count ? __hip_atomic_load(row + (size_t)(c0 + w) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+						      : tag;
 #pragma unroll
 			for (u32 w = 0; w < 8u; w++)
 				again = again || (u32)(s[w] >> 32) != epoch;
@@ -108,7 +109,7 @@ __device__ __forceinline__ u32 d_rs_wait_sum(const u64w *row, u32 count, u32 epo
 	return sum;
 }
 
-// look:  [chunk][digit][RS_CHUNK] tile counts;  look2: [digit][chunk_cap] chunk sums;  ctl: {ticket, finished}
+// look:  [tile][digit] tile counts;  look2: [chunk][digit] chunk sums;  ctl: {ticket, finished}
 __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
 							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
 							 u32 dmask, u32 *hist, u64w *look, u64w *look2, u32 chunk_cap, u32 *ctl,
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 	for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS)
 		(&s_cnt[0][0])[i] = 0;
 	__syncthreads();
-	const u32 tile = s_tile;
+	const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile); // (uniform: row bases and loop bounds stay in scalar registers)
 	const u32 base = tile * RS_TILE;
 	// (a launch sized by the capacity: a tile beyond the pairs holds nothing, and no tile waits for a later one)
 	if (base < n) {
@@ -179,17 +180,16 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 	const u32 gdigit = d_block_excl_scan(digit ? hist[t] : 0u, s_part);
 	if (digit) {
 		// digit t: offset of this tile = counts of all tiles before it, combined in two levels (no chain)
-		const u32 chunk = tile / RS_CHUNK, nb = tile - chunk * RS_CHUNK;
+		const u32 chunk = tile / RS_CHUNK, first = chunk * RS_CHUNK, nb = tile - first;
 		const u64w tag = (u64w)epoch << 32;
-		u64w *row = look + ((size_t)chunk * RS_BINS + t) * RS_CHUNK; // this digit's counts of the chunk's 16 tiles
-		__hip_atomic_store(row + nb, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(look + (size_t)tile * RS_BINS + t, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		// the tiles before this one inside its chunk (they hold lower tickets: they run or have finished)
-		u32 excl = d_rs_wait_sum(row, nb, epoch);
-		u64w *row2 = look2 + (size_t)t * chunk_cap; // this digit's chunk sums
+		u32 excl = d_rs_wait_sum(look + (size_t)first * RS_BINS + t, nb, RS_BINS, epoch);
 		if (nb == RS_CHUNK - 1u) // the chunk is complete with this tile: publish its sum
-			__hip_atomic_store(row2 + chunk, tag | (u64w)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(look2 + (size_t)chunk * RS_BINS + t, tag | (u64w)(excl + total), __ATOMIC_RELAXED,
+					   __HIP_MEMORY_SCOPE_AGENT);
 		// the chunks before this one (their last tiles hold lower tickets)
-		excl += d_rs_wait_sum(row2, chunk, epoch);
+		excl += d_rs_wait_sum(look2 + t, chunk, RS_BINS, epoch);
 		s_lstart[t] = lstart;
 		s_base[t] = gdigit + excl - lstart;
 	} // digit
@@ -242,7 +242,7 @@ static int rs_state(ugrt_ctx *ctx, u32 tiles)
 {
 	// [RS_SITES] site blocks, then the look-back words of the running pass: tile counts, chunk sums
 	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
-	const size_t look_words64 = (size_t)chunks * RS_BINS * RS_CHUNK + (size_t)RS_BINS * chunks;
+	const size_t look_words64 = (size_t)chunks * RS_CHUNK * RS_BINS + (size_t)chunks * RS_BINS;
 	const size_t bytes = (size_t)RS_SITES * RS_SITE_WORDS * 4 + look_words64 * 8;
 	const void *before = ctx->rs_state.p;
 	if (bytes <= ctx->rs_state.cap)
@@ -321,7 +321,7 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 	u32 *hist = sitep, *ctl = sitep + RS_MAXPASS * RS_BINS;
 	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
 	u64w *look = (u64w *)((u32 *)ctx->rs_state.p + (size_t)RS_SITES * RS_SITE_WORDS);
-	u64w *look2 = look + (size_t)chunks * RS_BINS * RS_CHUNK;
+	u64w *look2 = look + (size_t)chunks * RS_CHUNK * RS_BINS;
 	if (!prehist) {
 		RsHist h;
 		h.hist = hist;

@@ -1531,7 +1531,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		mbits = (u32)ctx->opt[UGRT_OPT_SHADOW_MBITS];
 	mbits = mbits > 24u ? 24u : mbits;
 	// the kernels that write sort keys also count their digits (ugrt_rs_hist.h), unless the library's sort is asked for
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1;
+	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] != 0;
 	const RsHist hs_none = { nullptr, 0u, 0 };
 	const u32 kblocks = (u32)((n + WL_THREADS - 1) / WL_THREADS) < 768u ? (u32)((n + WL_THREADS - 1) / WL_THREADS) : 768u;
 	if (key64) {
@@ -1543,13 +1543,13 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			return rc;
 	} else {
 		RsHist hs = hs_none;
-		if (own_sort && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_RAYS, (int)(mbits + cellbits), &hs)))
+		if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_RAYS, (int)(mbits + cellbits), &hs)))
 			return rc;
 		hipLaunchKernelGGL(k_shadow_keys<false>, dim3(kblocks), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
 				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity, hs);
 		UGRT_HIP(hipGetLastError());
-		if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_RAYS, true, (const u32 *)k0, (u32 *)k1, v0, v1, n,
+		if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_RAYS, fused, (const u32 *)k0, (u32 *)k1, v0, v1, n,
 							  (int)(mbits + cellbits), nullptr)
 				   : ugrt_prim_sort_pairs(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits))))
 			return rc;
@@ -1644,7 +1644,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 					   (const GBox *)boxes, segcnt, segcap, (u32 *)ctx->tkey[1].p, (u32 *)ctx->tval[1].p, sbits,
 					   (const CullItem *)ctx->citem.p);
 		RsHist hsp = hs_none; // (the width of the pair keys depends on the beam count, which the waiting form learns later)
-		if (own_sort) {
+		if (fused) {
 			if (attempt > 0 && (rc = ugrt_sort_hist_reset(ctx, RS_SITE_SHADOW_PAIRS))) // the first attempt's counts
 				return rc;
 			if ((rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_PAIRS, 32, &hsp)))
@@ -1699,12 +1699,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		ctx->h_pinned[UGRT_PIN_SHADOW + 1] = G;
 		ctx->shadow_async_pending = false;
 		if (P == 0 || G == 0)
-			return own_sort ? ugrt_sort_hist_reset(ctx, RS_SITE_SHADOW_PAIRS) : UGRT_OK; // (no pairs: nothing was counted)
+			return fused ? ugrt_sort_hist_reset(ctx, RS_SITE_SHADOW_PAIRS) : UGRT_OK; // (no pairs: nothing was counted)
 		xcap = (G + P / XSEG) * (beam / 64u); // >= number of exact-pass items
 	}
 	// 3. candidates by beam
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
-	if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_PAIRS, true, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p,
+	if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_PAIRS, fused, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p,
 						  (const u32 *)ctx->tval[0].p, (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)
 			   : ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
 						  (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)))
@@ -1726,7 +1726,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	u32 *iseg0 = (u32 *)ctx->sitem.p, *isub0 = iseg0 + xcap, *iseg1 = isub0 + xcap, *isub1 = iseg1 + xcap;
 	const bool item_sort = ctx->opt[UGRT_OPT_SHADOW_ITEMSORT] != 0;
 	RsHist hsi = hs_none;
-	if (item_sort && own_sort && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_ITEMS, 8, &hsi)))
+	if (item_sort && fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_ITEMS, 8, &hsi)))
 		return rc;
 	{
 		const u32 ib = (xcap + WL_THREADS - 1) / WL_THREADS;
@@ -1736,7 +1736,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	}
 	UGRT_HIP(hipGetLastError());
 	if (item_sort) {
-		if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_ITEMS, true, iseg0, iseg1, isub0, isub1, xcap, 8, nullptr)
+		if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_ITEMS, fused, iseg0, iseg1, isub0, isub1, xcap, 8, nullptr)
 				   : ugrt_prim_sort_pairs(ctx, iseg0, iseg1, isub0, isub1, xcap, 8)))
 			return rc;
 	} else {

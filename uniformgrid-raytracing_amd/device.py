@@ -107,7 +107,8 @@ class Context:
         return gi
 
     def set_face_window(self, begin, end):
-        """Triangles [begin, end) the light / uniform builds bin (0, 0 = all): this rank's shard of the build."""
+        """Triangles [begin, end) the light / uniform builds bin (end < 0: to the last one; 0, -1 = all; begin == end:
+        none): this rank's shard of the build."""
         check(lib.ugrt_ctx_set_face_window(self._h, int(begin), int(end)))
 
     def grid_merge_shards(self, which, keys, vals, spans, counts):

@@ -76,7 +76,6 @@ class Renderer:
             # the bounce runs beside the ray sort and the shadow pass and has slack: four persistent waves per CU leave
             # the registers and LDS of every CU to the main stream's workgroups (with the whole chip taken by
             # the bounce's waves, a sort pass of the main stream waited 0.2 ms for room)
-            self.aux.set_option("dda_rays_per_wave", 64)
             self.aux.set_option("dda_blocks", 1024)
             import queue
             import threading
@@ -401,19 +400,30 @@ class Renderer:
 
         ctx, sh = self.ctx, self.shards
         ctx.set_face_window(*face_window(sh.rank, sh.world, self.F))
-        build()
-        value, key, span, offset, gi = ctx.grid_arrays(which)
-        ks, vs, sps, counts = sh.exchange(key, value, span, gi.total_refs)
-        if sh.world == 1:  # the parts must not be the context's own arrays
-            ks, vs, sps = [ks[0].clone()], [vs[0].clone()], [sps[0].clone()]
-        ctx.grid_merge_shards(which, ks, vs, sps, counts)
-        self._shard_parts = (ks, vs, sps)  # alive until the merge has run
-        ctx.set_face_window(0, 0)
+        try:
+            build()
+            value, key, span, offset, gi = ctx.grid_arrays(which)
+            ks, vs, sps, counts = sh.exchange(key, value, span, gi.total_refs)
+            if sh.world == 1:  # the parts must not be the context's own arrays
+                ks, vs, sps = [ks[0].clone()], [vs[0].clone()], [sps[0].clone()]
+            ctx.grid_merge_shards(which, ks, vs, sps, counts)
+            self._shard_parts = (ks, vs, sps)  # alive until the merge has run
+        finally:
+            ctx.set_face_window(0, -1)  # whatever happened: later builds bin every triangle again
 
     def synchronize(self):
-        self.ctx.synchronize()
-        if self.aux is not None:
-            self.aux.synchronize()
+        """Both contexts are synchronised before anything is raised: an overflow reported by one must not leave the
+        other's report pending (it would be raised again after the frames had been repeated)."""
+        err = None
+        for c in (self.ctx, self.aux):
+            if c is None:
+                continue
+            try:
+                c.synchronize()
+            except Exception as e:  # UGRT_EOVERFLOW of either context: one report for the pair
+                err = err or e
+        if err is not None:
+            raise err
 
     def band_image(self):
         """uint8 view [rows*8, W, 3] of this context's band."""

@@ -1115,6 +1115,33 @@ def test_async_builds_equal_the_waiting_form(ugrt, O, torch):
     np.testing.assert_array_equal(r3.image.cpu().numpy(), r4.image.cpu().numpy())
 
 
+@pytest.mark.parametrize("async_build", [0, 1])
+def test_fused_sort_histograms(ugrt, O, torch, async_build):
+    """Option "sort_fused_hist": the kernels that write sort keys (fill, shadow keys, pair compaction, item list) count
+    the keys' digits for the sort that follows instead of a histogram kernel reading them again; the sorts' state
+    cleans itself.  Same frame, several times in a row (the rows must be zero again after every sort)."""
+    s = scene(ugrt, "crash")
+    W, H, lg, ud = 256, 144, (64, 64), (32, 32, 16)
+    setup = setup_for(ugrt, s, "ref")
+    ctx, r = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    ctx.set_option("sort_fused_hist", 1)
+    ctx.set_option("async_build", async_build)
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud, all_chunks=True)
+    for k in range(4):
+        if k == 2:
+            ctx.set_option("sort_fused_hist", 0)  # and back: both forms share the rows of a site
+        if k == 3:
+            ctx.set_option("sort_fused_hist", 1)
+        r.display(setup, shadows=True, reflect=True)
+        ctx.synchronize()
+        for n, key in (("intersect_id", "mat_ids"), ("is_shadowed", "is_shadowed"), ("hit_id", "hit_id"), ("image", "image")):
+            np.testing.assert_array_equal(getattr(r, n).cpu().numpy(), want[key], err_msg="%s frame %d" % (n, k))
+        for which, g in ((ugrt.GRID_PERSPECTIVE, "grid"), (ugrt.GRID_SPHERICAL, "lgrid"), (ugrt.GRID_UNIFORM, "ugrid")):
+            value, key, span, offset, gi = ctx.grid_arrays(which)
+            np.testing.assert_array_equal(u32(key), want[g]["keys"])
+            np.testing.assert_array_equal(u32(value), want[g]["vals"])
+
+
 def test_async_build_growth_between_launch_size_and_buffer_capacity(ugrt, O, torch):
     """A grid (and the shadow pass's pair list) that grows by about a third from one frame to the next: more than the
     launches of an asynchronous build are sized for (the last need + 25 % + 64 K), less than the grow-only buffers

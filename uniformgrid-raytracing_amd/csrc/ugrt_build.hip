@@ -714,7 +714,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, (const u32 *)rw);
 	// (the fill also accumulates the digit histograms of the sort of its keys)
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] != 0;
+	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
 	RsHist hs = { nullptr, 0u, 0 };
 	if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gi, bits_for(C), &hs)))
 		return rc;
@@ -840,7 +840,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p, (const u32 *)nullptr);
 		const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1 && Rn <= (1u << 30);
-		const bool fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] != 0;
+		const bool fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
 		RsHist hs = { nullptr, 0u, 0 };
 		if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gidx, bits_for(C), &hs)))
 			return rc;

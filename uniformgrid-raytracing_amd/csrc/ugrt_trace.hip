@@ -1531,7 +1531,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		mbits = (u32)ctx->opt[UGRT_OPT_SHADOW_MBITS];
 	mbits = mbits > 24u ? 24u : mbits;
 	// the kernels that write sort keys also count their digits (ugrt_rs_hist.h), unless the library's sort is asked for
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] != 0;
+	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
 	const RsHist hs_none = { nullptr, 0u, 0 };
 	const u32 kblocks = (u32)((n + WL_THREADS - 1) / WL_THREADS) < 768u ? (u32)((n + WL_THREADS - 1) / WL_THREADS) : 768u;
 	if (key64) {

@@ -332,15 +332,33 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_count_uniform(UGrid g, const 
 // cache lines per wave in its last steps and was bound by the address path, not by bytes).
 #define FILL_LDS 1024
 // (counts that the host does not know - an asynchronous build - are read from `rw` = {narrow references, wide
-// triangles}, already checked against the capacities by k_build_check)
+// triangles}, already checked against the capacities by k_fill_parts)
+// (asynchronous build: `chk` carries the check -- the counts behind the scan against the
+// capacities the launches were sized for; every thread derives the checked count itself, thread 0 publishes it)
+struct BuildCheck {
+	const u32 *scan_last; // {narrow references, wide triangles}; nullptr = the host knows the counts
+	u32 capRn, capW;
+	unsigned long long capR, active;
+	u32 *rw, *status, *report;
+};
 __global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restrict__ scan, int F, u32 R, u32 nparts,
-							       u32 *__restrict__ parts, const u32 *__restrict__ rw)
+							       u32 *__restrict__ parts, BuildCheck chk)
 {
-	if (rw) {
-		R = rw[0];
+	const u32 b = blockIdx.x * BUILD_THREADS + threadIdx.x;
+	if (chk.scan_last) {
+		u32 Rn = chk.scan_last[0], W = chk.scan_last[1];
+		const bool over = Rn > chk.capRn || W > chk.capW || (unsigned long long)Rn + chk.active * W > chk.capR;
+		if (b == 0u) {
+			chk.report[0] = Rn; // what the build needed: the next build's estimate
+			chk.report[1] = W;
+			if (over)
+				atomicOr(chk.status, UGRT_STATUS_BUILD_OVERFLOW);
+			chk.rw[0] = over ? 0u : Rn; // an overflowing build is emptied: nothing is written out of bounds
+			chk.rw[1] = over ? 0u : W;
+		}
+		R = over ? 0u : Rn;
 		nparts = (R + BUILD_THREADS - 1) / BUILD_THREADS;
 	}
-	const u32 b = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (b > nparts || R == 0u)
 		return;
 	u32 target = b * BUILD_THREADS; // first reference of workgroup b; parts[nparts] closes the last one
@@ -619,26 +637,10 @@ static int bits_for(u32 C)
 // Asynchronous build (option "async_build"): no read-back, the host never waits.  The counts the reference reads
 // back (total_triangles, frustum_grid.h:254) stay on the device; launches and buffers are sized by what the same
 // grid needed in the previous build plus a margin, and every kernel takes the real counts from device memory.
-// k_build_check compares them with the capacities first: when they do not fit, the build is emptied (nothing is
+// k_fill_parts compares them with the capacities first: when they do not fit, the build is emptied (nothing is
 // written out of bounds) and a status bit is raised, which the host sees at its next synchronisation
 // (UGRT_EOVERFLOW; the following build of the grid runs synchronously and sizes the buffers exactly).
 // ---------------------------------------------------------------------------
-__global__ void k_build_check(const u32 *__restrict__ scan_last, u32 capRn, u32 capW, unsigned long long capR,
-			      unsigned long long active, u32 *__restrict__ rw, u32 *__restrict__ status,
-			      u32 *__restrict__ report)
-{
-	u32 Rn = scan_last[0], W = scan_last[1];
-	report[0] = Rn; // what the build needed: the next build's estimate
-	report[1] = W;
-	if (Rn > capRn || W > capW || (unsigned long long)Rn + active * W > capR) {
-		atomicOr(status, UGRT_STATUS_BUILD_OVERFLOW);
-		Rn = 0;
-		W = 0;
-	}
-	rw[0] = Rn;
-	rw[1] = W;
-}
-
 // the tail of an asynchronous build's report when no merge kernel runs (see k_merge_wide)
 __global__ void k_report_tail(u32 *__restrict__ report_tail, const u32 *__restrict__ used, const u32 *__restrict__ status)
 {
@@ -699,9 +701,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	// against THIS size, not against the (larger, grow-only) buffers: fill, sort, bounds and merge run one thread per
 	// reference of the launch, so a count between the two would leave references unfilled and unsorted.
 	const u32 launchRn = estRn + estRn / 4u + 65536u < capRn ? estRn + estRn / 4u + 65536u : capRn;
-	hipLaunchKernelGGL(k_build_check, dim3(1), dim3(1), 0, st, (const u32 *)G.scan.p + (F - 1), launchRn, capW, capR, active,
-			   rw, status, report);
-	UGRT_HIP(hipGetLastError());
+	BuildCheck chk = { (const u32 *)G.scan.p + (F - 1), launchRn, capW, capR, active, rw, status, report };
 	WideBox wb;
 	wb.W = 0;
 	wb.ny = (u32)ny;
@@ -712,7 +712,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	const u32 nparts = (launchRn + BUILD_THREADS - 1) / BUILD_THREADS;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, (const u32 *)rw);
+			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, chk);
 	// (the fill also accumulates the digit histograms of the sort of its keys)
 	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
 	RsHist hs = { nullptr, 0u, 0 };
@@ -838,7 +838,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 		const u32 nparts = (Rn + BUILD_THREADS - 1) / BUILD_THREADS;
 		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p, (const u32 *)nullptr);
+				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p, BuildCheck{ nullptr, 0u, 0u, 0ull, 0ull, nullptr, nullptr, nullptr });
 		const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1 && Rn <= (1u << 30);
 		const bool fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
 		RsHist hs = { nullptr, 0u, 0 };

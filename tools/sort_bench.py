@@ -20,15 +20,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--items", type=int, default=0, help='option "sort_items" (pairs per thread of a pass: 8 or 16)')
+    ap.add_argument("--quick", action="store_true", help="16- and 32-bit random keys only")
     args = ap.parse_args()
     import torch
     import ugrt
 
     ctx = ugrt.Context(256, 256, device=0)
+    if args.items:
+        ctx.set_option("sort_items", args.items)
     rows = []
     for n in (1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23):
-        for bits in (8, 16, 24, 32):
-            for shape in ("random", "runs"):
+        for bits in ((16, 32) if args.quick else (8, 16, 24, 32)):
+            for shape in (("random",) if args.quick else ("random", "runs")):
                 g = torch.Generator(device="cuda").manual_seed(n ^ bits)
                 hi = (1 << bits) - 1
                 if shape == "random":

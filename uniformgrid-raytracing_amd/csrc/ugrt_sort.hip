@@ -28,8 +28,7 @@
 
 #define RS_THREADS 512
 #define RS_WAVES (RS_THREADS / 64)
-#define RS_ITEMS 16
-#define RS_TILE (RS_THREADS * RS_ITEMS)
+#define RS_ITEMS_MAX 16 // pairs per thread: 16 (tiles of 8192 pairs) or 8 (4096: option "sort_items")
 #define RS_CHUNK 16 // tiles per chunk of the two-level offset computation
 
 // state of one site (u32 words): histogram rows, then per pass {ticket, finished workgroups}
@@ -84,39 +83,42 @@ __device__ __forceinline__ u32 d_block_excl_scan(u32 v, u32 *s_part)
 }
 
 // sum over `count` rows of the look-back word of this thread's digit (rows `stride` words apart, the first at `row`),
-// each awaited until it carries this pass's epoch; eight loads in flight at a time
+// each awaited until it carries this pass's epoch; GROUP loads in flight at a time
+template <int GROUP>
 __device__ __forceinline__ u32 d_rs_wait_sum(const u64w *row, u32 count, u32 stride, u32 epoch)
 {
 	const u64w tag = (u64w)epoch << 32;
 	u32 sum = 0;
-	for (u32 c0 = 0; c0 < count; c0 += 8u) {
-		u64w s[8];
+	for (u32 c0 = 0; c0 < count; c0 += (u32)GROUP) {
+		u64w s[GROUP];
 		bool again;
 		do {
 			again = false;
 #pragma unroll
-			for (u32 w = 0; w < 8u; w++)
+			for (u32 w = 0; w < (u32)GROUP; w++)
 				s[w] = c0 + w < count ? __hip_atomic_load(row + (size_t)(c0 + w) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 						      : tag;
 #pragma unroll
-			for (u32 w = 0; w < 8u; w++)
+			for (u32 w = 0; w < (u32)GROUP; w++)
 				again = again || (u32)(s[w] >> 32) != epoch;
 		} while (again);
 #pragma unroll
-		for (u32 w = 0; w < 8u; w++)
+		for (u32 w = 0; w < (u32)GROUP; w++)
 			sum += (u32)s[w];
 	}
 	return sum;
 }
 
 // look:  [tile][digit] tile counts;  look2: [chunk][digit] chunk sums;  ctl: {ticket, finished}
-__global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
+template <int RS_ITEMS>
+__global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
 							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
 							 u32 dmask, u32 *hist, u64w *look, u64w *look2, u32 chunk_cap, u32 *ctl,
 							 u32 epoch, const u32 *__restrict__ n_dev, u32 rows_to_clear)
 {
 	if (n_dev)
 		n = *n_dev < n ? *n_dev : n;
+	constexpr u32 RS_TILE = RS_THREADS * RS_ITEMS;
 	__shared__ u32 s_keys[RS_TILE], s_vals[RS_TILE];
 	__shared__ u32 s_cnt[RS_WAVES][RS_BINS]; // per wave: digit counters while ranking, then the wave's offset inside the digit
 	__shared__ u32 s_lstart[RS_BINS]; // first slot of the digit inside the sorted tile
@@ -138,6 +140,15 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 	for (int i = 0; i < RS_ITEMS; i++) {
 		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
 		k[i] = idx < n ? kin[idx] : 0xFFFFFFFFu;
+	}
+	// (small tiles have the registers to fetch the values beside the keys; large ones fetch them behind the look-back)
+	u32 v[RS_ITEMS];
+	if (RS_ITEMS <= 8) {
+#pragma unroll
+		for (int i = 0; i < RS_ITEMS; i++) {
+			const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
+			v[i] = idx < n ? vin[idx] : 0u;
+		}
 	}
 	// wave-synchronous ranking, items in memory order
 	volatile u32 *cnt = s_cnt[wave];
@@ -184,22 +195,23 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_rs_pass(const u32 *__restrict
 		const u64w tag = (u64w)epoch << 32;
 		__hip_atomic_store(look + (size_t)tile * RS_BINS + t, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		// the tiles before this one inside its chunk (they hold lower tickets: they run or have finished)
-		u32 excl = d_rs_wait_sum(look + (size_t)first * RS_BINS + t, nb, RS_BINS, epoch);
+		u32 excl = d_rs_wait_sum<(RS_ITEMS > 8 ? 8 : 4)>(look + (size_t)first * RS_BINS + t, nb, RS_BINS, epoch);
 		if (nb == RS_CHUNK - 1u) // the chunk is complete with this tile: publish its sum
 			__hip_atomic_store(look2 + (size_t)chunk * RS_BINS + t, tag | (u64w)(excl + total), __ATOMIC_RELAXED,
 					   __HIP_MEMORY_SCOPE_AGENT);
 		// the chunks before this one (their last tiles hold lower tickets)
-		excl += d_rs_wait_sum(look2 + t, chunk, RS_BINS, epoch);
+		excl += d_rs_wait_sum<(RS_ITEMS > 8 ? 8 : 4)>(look2 + t, chunk, RS_BINS, epoch);
 		s_lstart[t] = lstart;
 		s_base[t] = gdigit + excl - lstart;
 	} // digit
 	__syncthreads();
 	// tile in digit order in LDS (the values are fetched only now: they would occupy registers all the way)
-	u32 v[RS_ITEMS];
+	if (RS_ITEMS > 8) {
 #pragma unroll
-	for (int i = 0; i < RS_ITEMS; i++) {
-		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
-		v[i] = idx < n ? vin[idx] : 0u;
+		for (int i = 0; i < RS_ITEMS; i++) {
+			const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
+			v[i] = idx < n ? vin[idx] : 0u;
+		}
 	}
 #pragma unroll
 	for (int i = 0; i < RS_ITEMS; i++) {
@@ -306,6 +318,10 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 	if (end_bit > 32)
 		end_bit = 32;
 	const int passes = (end_bit + 7) / 8;
+	// pairs per thread: tiles of 4096 pairs finish a pass of up to ~1 M pairs in 15-23 us (8192: 18-25), tiles of 8192
+	// are faster from 2 M on (30 against 35 us, 44 against 65 at 4 M: half the tickets and look-back rows)
+	const int items = ctx->opt[UGRT_OPT_SORT_ITEMS] > 0 ? (ctx->opt[UGRT_OPT_SORT_ITEMS] == 8 ? 8 : 16) : (n <= (3u << 18) ? 8 : 16);
+	const u32 RS_TILE = (u32)(RS_THREADS * items);
 	const u32 tiles = n ? (u32)((n + RS_TILE - 1) / RS_TILE) : 1u; // (n == 0 with histogram rows to clear: one idle tile)
 	hipStream_t st = ctx->stream;
 	int rc;
@@ -342,9 +358,14 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 			UGRT_HIP(hipMemsetAsync(look, 0, ctx->rs_state.cap - (size_t)RS_SITES * RS_SITE_WORDS * 4, st));
 			ctx->rs_epoch = 1;
 		}
-		hipLaunchKernelGGL(k_rs_pass, dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),
-				   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,
-				   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u);
+		if (items == 8)
+			hipLaunchKernelGGL(k_rs_pass<8>, dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),
+					   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,
+					   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u);
+		else
+			hipLaunchKernelGGL(k_rs_pass<16>, dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),
+					   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,
+					   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u);
 		UGRT_HIP(hipGetLastError());
 		ki = ko;
 		vi = vo;

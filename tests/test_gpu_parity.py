@@ -756,6 +756,58 @@ def test_full_size_bench_workload(ugrt, O, torch):
     assert (pr["id"][a:b] >= 0).sum() > 1000 and want["is_shadowed"][a:b].sum() > 100
 
 
+def test_bench_setting_four_renderers_in_flight(ugrt, O, torch):
+    """The setting bench.py times by default, built here piece by piece: 1 M triangles at 1920x1080, FOUR renderers
+    (each two contexts on two streams fed by this one host thread: overlap=True, helper_thread=False), builds and
+    shadow pass that never wait (async_build), the bounce on 3072 persistent waves, the shadow kernels on 4096,
+    UGRT_FLAG_STATIC_GEOMETRY.  Eight steps are dealt round-robin without a synchronisation in between; afterwards
+    every renderer's buffers are compared with the CPU restatement on a band of tile rows, bit for bit, and with one
+    another over the whole frame."""
+    import bench
+
+    s = ugrt.scenes.crash(scale=1.0)
+    W, H, lg, ud = 1920, 1080, (128, 128), (128, 128, 64)
+    setup = setup_for(ugrt, s, "ref")
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY
+    renderers = []
+    for i in range(4):
+        stream = torch.cuda.Stream() if i else None
+        with torch.cuda.stream(stream):
+            cx = ugrt.Context(W, H, light_grid=lg, flags=flags, uniform_dims=ud)
+            rr = ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True,
+                               helper_thread=False)
+        rr._stream = stream
+        rr.aux.set_option("dda_blocks", bench.DDA_WAVES_THROUGHPUT)
+        rr.ctx.set_option("shadow_waves", bench.SHADOW_WAVES_THROUGHPUT)
+        for c in (rr.ctx, rr.aux):
+            c.set_option("async_build", 1)
+        renderers.append(rr)
+    for k in range(8):
+        rr = renderers[k % 4]
+        with torch.cuda.stream(rr._stream):
+            rr.display(setup, frame_cnt=1, shadows=True, reflect=True)
+    for rr in renderers:
+        rr.synchronize()  # (raises if an estimate overflowed: none may, the frames are identical)
+    torch.cuda.synchronize()
+    rows = (60, 64)
+    want = O.frame(s, setup, W, H, rows=rows, light_grid=lg, all_chunks=True, reflect=True, uniform_dims=ud)
+    a, b = want["p0"], want["p0"] + want["n"]
+    pr = want["primary"]
+    first = renderers[0]
+    for i, rr in enumerate(renderers):
+        what = "renderer %d" % i
+        np.testing.assert_array_equal(rr.t.cpu().numpy()[a:b].view(np.uint32), pr["t"][a:b].view(np.uint32), err_msg=what)
+        np.testing.assert_array_equal(rr.is_shadowed.cpu().numpy()[a:b], want["is_shadowed"][a:b], err_msg=what)
+        np.testing.assert_array_equal(rr.intersect_id.cpu().numpy()[a:b], want["mat_ids"][a:b], err_msg=what)
+        np.testing.assert_array_equal(rr.hit_id.cpu().numpy()[a:b], want["hit_id"][a:b], err_msg=what)
+        np.testing.assert_array_equal(rr.hit_t.cpu().numpy()[a:b].view(np.uint32), want["hit_t"][a:b].view(np.uint32), err_msg=what)
+        np.testing.assert_array_equal(rr.image.cpu().numpy()[3 * a:3 * b], want["image"][3 * a:3 * b], err_msg=what)
+        if i:
+            for n in ("t", "is_shadowed", "intersect_id", "hit_id", "hit_t", "image", "normal", "dir"):
+                assert torch.equal(getattr(rr, n).view(torch.uint8), getattr(first, n).view(torch.uint8)), (what, n)
+    assert (pr["id"][a:b] >= 0).sum() > 1000 and want["is_shadowed"][a:b].sum() > 100 and want["active"][a:b].sum() > 100
+
+
 def test_4k_frame_bands_and_oracle(ugrt, O, torch):
     """BASELINE configs[3]: the 1 M-triangle scene at 3840x2160 (129 600 screen cells: 17-bit sort keys, three
     radix passes).  The full frame on one context, the same frame as two half-image bands (the multi-GPU

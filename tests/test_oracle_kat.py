@@ -1,5 +1,8 @@
 """Known answers that pin the oracle.  The reference ships no tests; SURVEY.md section 8(c) records three
-observations made by running the reference's kernels, which are the only reference outputs available:
+observations made by running the reference's kernels, which are the only reference outputs available.
+They are TRANSCRIBED from that prose: the probe that produced them lived outside the repository (a host-side shim
+around the reference's .cu files, which this project's rules do not allow to be rebuilt), so no committed script
+regenerates them; the inputs below are re-created from the survey's description of each probe.
  (1) one triangle with ndc x,y in [-0.5,0.5] on the 128x128 grid -> sizeList = 65*65 = 4225 (DSKernel);
  (2) centre tile, one triangle at z=-5 -> 64/64 hits, t=5, n=(0,0,1), dir=(0,0,-1), id 0 (rckernel_alpha);
  (3) a backward ray returns t=+1 from intersectTriUV (abs) and t=-1 from intersectTri (signed).

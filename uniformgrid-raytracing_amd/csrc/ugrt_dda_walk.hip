@@ -85,6 +85,44 @@ __global__ __launch_bounds__(256) void k_dda_sort_keys(DGrid g, const float *__r
 	keys[i] = (cell << 3) | oct;
 }
 
+// Lane selects by a 64-bit lane mask held in a scalar register pair (a bit set = take the second value): one
+// v_cndmask each.  The plan's step is written with these and with masks from __ballot: a step is three compares, a
+// handful of scalar mask operations and ~25 selects/adds.  (As C++ `bool`s the compiler turned every mask into a
+// 0/1 lane value and back: ~60 vector instructions per step, and the plan was 30 % of the kernel's.)
+typedef unsigned long long m64;
+__device__ __forceinline__ float d_msel(float a, float b, m64 m)
+{
+	float r;
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+	return r;
+}
+__device__ __forceinline__ u32 d_msel(u32 a, u32 b, m64 m)
+{
+	u32 r;
+	asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+	return r;
+}
+__device__ __forceinline__ u32 d_msel0(u32 b, m64 m) // m ? b : 0
+{
+	u32 r;
+	asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(b), "s"(m));
+	return r;
+}
+__device__ __forceinline__ u32 d_mbit(m64 m) // m ? 1 : 0
+{
+	u32 r;
+	asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+	return r;
+}
+// bit offset of the chosen axis' field in the packed step counters: axis 0 -> 0, 1 -> 10, 2 -> 20
+__device__ __forceinline__ u32 d_axis_shift(m64 a0, m64 a1)
+{
+	u32 r, q;
+	asm("v_cndmask_b32_e64 %0, 20, 10, %1" : "=v"(q) : "s"(a1));
+	asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(r) : "v"(q), "s"(a0));
+	return r;
+}
+
 #define WK_STAMP(PH)                                                          \
 	do {                                                                  \
 		if (COUNT) {                                                  \
@@ -127,7 +165,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 		// ray leaves the grid (0 for an axis the ray does not move along: choosing it ends the walk, as in the
 		// specification's `step == 0 || c out of range`)
 		float tmax[3] = { 0, 0, 0 }, tdelta[3] = { 0, 0, 0 };
-		u32 cidx = 0u, rem[3] = { 0, 0, 0 };
+		u32 cidx = 0u, remp = 0u; // remp: the three axes' steps left, 10 bits each
 		int cstep[3] = { 0, 0, 0 };
 		int w0 = 0; // phase of the ray's first cell (alignment below)
 		float best_t = 3.0e38f, tcur = 0.0f;
@@ -175,13 +213,13 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 							tmax[k] = ((g.lo[k] + (float)(ck + 1) * g.cs[k]) - o[k]) / d[k];
 							tdelta[k] = g.cs[k] / d[k];
 							cstep[k] = stride[k];
-							rem[k] = (u32)(g.dims[k] - 1 - ck);
+							remp |= (u32)(g.dims[k] - 1 - ck) << (10 * k);
 							w0 += ck;
 						} else if (d[k] < 0.0f) {
 							tmax[k] = ((g.lo[k] + (float)ck * g.cs[k]) - o[k]) / d[k];
 							tdelta[k] = -g.cs[k] / d[k];
 							cstep[k] = -stride[k];
-							rem[k] = (u32)ck;
+							remp |= (u32)ck << (10 * k);
 							w0 -= ck;
 						} else {
 							tmax[k] = 3.0e38f;
@@ -219,40 +257,49 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			WK_STAMP(7);
 			// 1. plan WK_AHEAD steps (registers only) and look their cells up in the occupancy bitmap
 			const float tstart = tcur;
-			u32 pcell[WK_AHEAD], vmask = 0u, nem = 0u;
+			u32 pcell[WK_AHEAD], vmask, nem = 0u;
 			float ptn[WK_AHEAD];
-			bool ended = false;
+			bool ended;
 			{
-				bool planning = walking;
-				// A step is written without branches (every lane executes the same ~30 instructions; with the axis
-				// chosen by `if` the three paths ran one after the other and the plan was the kernel's largest phase):
-				// axis = (tx < ty) ? ((tx < tz) ? x : z) : ((ty < tz) ? y : z), as in the specification.
+				// masks: P = rays still planning, E = rays that leave the grid in this window
+				m64 P = __ballot(walking), E = 0ull;
+				const float tstop = best_ref != WK_NONE ? best_t : __builtin_huge_valf(); // the hit carried along
+				const u32 vfirst = (u32)lag; // a ray ahead of its cluster waits `lag` steps first (first window only)
+				u32 vcount = 0u;
+				const bool lagging = __ballot(lag > 0) != 0ull;
+				// axis = (tx < ty) ? ((tx < tz) ? x : z) : ((ty < tz) ? y : z), as in the specification
 #pragma unroll
 				for (int q = 0; q < WK_AHEAD; q++) {
-					const bool act = planning && lag == 0; // a ray ahead of its cluster waits `lag` steps first
-					lag -= (planning && lag > 0) ? 1 : 0;
-					vmask |= (act ? 1u : 0u) << q;
+					m64 A = P;
+					if (lagging) { // (wave-uniform: only the first window of a group has waiting rays)
+						const m64 L = __ballot(lag > 0);
+						lag -= (int)d_mbit(P & L);
+						A = P & ~L;
+					}
 					pcell[q] = cidx;
-					const bool xy = tmax[0] < tmax[1], xz = tmax[0] < tmax[2], yz = tmax[1] < tmax[2];
-					const bool a0 = xy && xz, a1 = !xy && yz, a2 = !(a0 || a1);
-					const float tn = a0 ? tmax[0] : (a1 ? tmax[1] : tmax[2]);
-					const u32 left = a0 ? rem[0] : (a1 ? rem[1] : rem[2]);
-					const int cs = a0 ? cstep[0] : (a1 ? cstep[1] : cstep[2]);
-					const bool outside = left == 0u;
-					tcur = act ? tn : tcur;
-					cidx = (act && !outside) ? cidx + (u32)cs : cidx;
-					tmax[0] = (act && a0) ? tmax[0] + tdelta[0] : tmax[0];
-					tmax[1] = (act && a1) ? tmax[1] + tdelta[1] : tmax[1];
-					tmax[2] = (act && a2) ? tmax[2] + tdelta[2] : tmax[2];
-					rem[0] -= (act && a0) ? 1u : 0u; // (wraps when the ray leaves: never read again)
-					rem[1] -= (act && a1) ? 1u : 0u;
-					rem[2] -= (act && a2) ? 1u : 0u;
+					const m64 xy = __ballot(tmax[0] < tmax[1]), xz = __ballot(tmax[0] < tmax[2]), yz = __ballot(tmax[1] < tmax[2]);
+					const m64 a0 = xy & xz, a1 = ~xy & yz;
+					const float tn = d_msel(d_msel(tmax[2], tmax[1], a1), tmax[0], a0);
+					const float tnew = tn + d_msel(d_msel(tdelta[2], tdelta[1], a1), tdelta[0], a0);
+					const u32 cs = d_msel(d_msel((u32)cstep[2], (u32)cstep[1], a1), (u32)cstep[0], a0);
+					const u32 sh = d_axis_shift(a0, a1);
+					const m64 out = __ballot((remp & (0x3FFu << sh)) == 0u); // no step left along the chosen axis: the ray leaves
+					tmax[0] = d_msel(tmax[0], tnew, A & a0);
+					tmax[1] = d_msel(tmax[1], tnew, A & a1);
+					tmax[2] = d_msel(tmax[2], tnew, A & ~(a0 | a1));
+					remp -= d_msel0(1u << sh, A); // (wraps when the ray leaves: never read again)
+					cidx += d_msel0(cs, A & ~out);
+					tcur = d_msel(tcur, tn, A);
+					vcount += d_mbit(A);
 					// the walk ends after this cell when the ray leaves the grid, and at the latest here when the hit carried
 					// along lies before this cell's exit
-					ended = ended || (act && outside);
-					planning = planning && !(act && (outside || (best_ref != WK_NONE && best_t <= tn)));
+					const m64 stop = __ballot(tstop <= tn);
+					E |= A & out;
+					P &= ~(A & (out | stop));
 					ptn[q] = tcur;
 				}
+				ended = (E >> lane) & 1ull;
+				vmask = ((1u << vcount) - 1u) << vfirst; // the steps this ray took: a run of `vcount` from `vfirst`
 				u32 bw[WK_AHEAD];
 #pragma unroll
 				for (int q = 0; q < WK_AHEAD; q++)

@@ -196,7 +196,7 @@ static const struct {
 	{ "shadow_xseg", 64, 1 << 20 }, { "shadow_sizebits", 0, 8 },    { "shadow_itemsort", 0, 1 },
 	{ "shadow_mbits", 1, 24 },      { "shadow_key64", 0, 1 },       { "sort_library", 0, 1 },
 	{ "async_build", 0, 1 },        { "primary_waves", 64, 1 << 20 },
-	{ "shadow_waves", 64, 1 << 20 }, { "dda_sort", 0, 1 }, { "sort_fused_hist", 0, 1 }, { "sort_items", 8, 16 }, { "dda_cull_work", 1, 1 << 30 },
+	{ "shadow_waves", 64, 1 << 20 }, { "dda_sort", 0, 1 }, { "sort_fused_hist", 0, 1 }, { "primary_order", 0, 1 }, { "primary_chunk", 4, 64 }, { "sort_items", 8, 16 }, { "dda_cull_work", 1, 1 << 30 },
 };
 
 extern "C" int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value)

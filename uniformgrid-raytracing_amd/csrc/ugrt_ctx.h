@@ -38,6 +38,8 @@ enum {
 	UGRT_OPT_SHADOW_WAVES,     // "shadow_waves": the same for the two shadow kernels
 	UGRT_OPT_DDA_SORT,         // "dda_sort": 1 = the bounce's ray list is sorted by (entry cell, octant) instead of tile order
 	UGRT_OPT_SORT_FUSED,       // "sort_fused_hist": 1 = the kernels that write sort keys count their digits (default 0: a histogram kernel per sort; measured faster)
+	UGRT_OPT_PRIMARY_ORDER,    // "primary_order": 0 = a flush's jobs run in list order (default 1: nearest triangles first)
+	UGRT_OPT_PRIMARY_CHUNK,    // "primary_chunk": jobs between two looks at the rays' closest hits (4..64)
 	UGRT_OPT_SORT_ITEMS,       // "sort_items": pairs per thread of a radix pass, 16 (tiles of 8192) or 8 (4096)
 	UGRT_OPT_DDA_CULL_WORK,    // "dda_cull_work": window kernel: (triangles x rays) of a job from which its list is culled first
 	UGRT_OPT_COUNT

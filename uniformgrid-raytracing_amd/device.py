@@ -250,7 +250,7 @@ class Context:
 
     PRIMARY_STATS = ("items", "batches", "batches_with_tile_survivors", "references", "tile_survivors",
                      "quadrant_survivors", "jobs", "flushes", "rounds", "rounds_to_division", "rounds_to_v",
-                     "rounds_to_t", "lane_tests", "hits")
+                     "rounds_to_t", "lane_tests", "hits", "jobs_behind_the_flush_s_final_hits", "jobs_dropped_by_the_depth_bound")
 
     def stats_primary(self):
         """Work counters of the primary tracer's last counting launch (a FLAG_COUNT_WORK context)."""

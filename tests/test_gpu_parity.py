@@ -759,7 +759,7 @@ def test_full_size_bench_workload(ugrt, O, torch):
 def test_bench_setting_four_renderers_in_flight(ugrt, O, torch):
     """The setting bench.py times by default, built here piece by piece: 1 M triangles at 1920x1080, FOUR renderers
     (each two contexts on two streams fed by this one host thread: overlap=True, helper_thread=False), builds and
-    shadow pass that never wait (async_build), the bounce on 3072 persistent waves, the shadow kernels on 4096,
+    shadow pass that never wait (async_build), the bounce on 3072 persistent waves of 64 rays, the shadow kernels on 4096,
     UGRT_FLAG_STATIC_GEOMETRY.  Eight steps are dealt round-robin without a synchronisation in between; afterwards
     every renderer's buffers are compared with the CPU restatement on a band of tile rows, bit for bit, and with one
     another over the whole frame."""
@@ -778,6 +778,7 @@ def test_bench_setting_four_renderers_in_flight(ugrt, O, torch):
                                helper_thread=False)
         rr._stream = stream
         rr.aux.set_option("dda_blocks", bench.DDA_WAVES_THROUGHPUT)
+        rr.aux.set_option("dda_rays_per_wave", bench.DDA_RPW_THROUGHPUT)
         rr.ctx.set_option("shadow_waves", bench.SHADOW_WAVES_THROUGHPUT)
         for c in (rr.ctx, rr.aux):
             c.set_option("async_build", 1)

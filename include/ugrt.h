@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define UGRT_VERSION 101
+#define UGRT_VERSION 102
 
 enum {
 	UGRT_OK = 0,
@@ -184,13 +184,19 @@ int ugrt_rot_cos_sin(float rot, float *c, float *s);
 int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cfg);
 int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
 /* launch-shape options of this context; none changes a result; value < 0 restores the default.  Keys:
- * "dda_kernel" 0 = beam kernel (rays of a wave share the work inside a cell), 1 = per-ray kernel;
- * "dda_rays_per_wave" 1..64 (0 = default); "dda_coop", "dda_cull_min" list lengths from which a lone ray's
- * cell is tested by the whole wave / a shared cell is culled before the exact tests; "primary_seg" triangles
- * per primary work item; "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits",
- * "shadow_key64" shape the shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix
- * sort instead of the built-in one; "dda_blocks", "primary_waves", "shadow_waves": number of persistent
- * single-wave workgroups of the bounce, the primary tracer and the two shadow kernels.
+ * "dda_kernel" 0 = window kernel (occupancy bitmap, jobs per occupied cell, (survivor, ray) pair rounds),
+ * 1 = per-ray kernel of round 1, 2 = beam kernel of round 2; "dda_rays_per_wave" 1..64 (0 = default: 32, beam
+ * kernel 64); "dda_cull_min" / "dda_cull_work": a job's list is culled against its ray bundle first from this
+ * many triangles / (triangles x rays) on; "dda_coop" (kernels 1 and 2) list length from which a lone ray's cell is
+ * tested by the whole wave; "dda_sort" 1 = the bounce's ray list sorted by (entry cell, octant) instead of tile
+ * order; "primary_seg" triangles per primary work item; "primary_order" 0 = a flush's jobs run in list order
+ * (default: nearest triangles first), "primary_chunk" jobs between two looks at the rays' closest hits;
+ * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64" shape the
+ * shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix sort instead of the built-in
+ * one, "sort_items" 8 / 16 pairs per thread of a radix pass (default: by size), "sort_fused_hist" 1 = the kernels
+ * that write sort keys count their digits (measured slower: DESIGN.md section 8); "dda_blocks", "primary_waves",
+ * "shadow_waves": number of persistent single-wave workgroups of the bounce, the primary tracer and the two
+ * shadow kernels.
  * "async_build" 1: the grid builds and ugrt_trace_shadow stop waiting for the device.  The reference reads
  * total_triangles back to size its lists (frustum_grid.h:254); here the second and later builds of a grid size
  * buffers and launches by what the build before needed plus a quarter, every kernel takes the real counts from

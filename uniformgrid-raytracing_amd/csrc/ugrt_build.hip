@@ -19,6 +19,7 @@
 // dropped.
 #include "ugrt_dev.h"
 #include "ugrt_rs_hist.h"
+#include "ugrt_scan.h"
 
 // cell range of one triangle: {x0 | x1 << 16, y0 | y1 << 16, z0 | z1 << 16}
 struct Rng {
@@ -481,35 +482,64 @@ __device__ __forceinline__ bool d_cell_active(const WideBox &wb, u32 c)
 	return y >= wb.ylo && y <= wb.yhi;
 }
 
-__global__ __launch_bounds__(BUILD_THREADS) void k_span(const u32 *__restrict__ cstart, u32 *__restrict__ span_io,
-							 u32 C, u32 *__restrict__ used, WideBox wb)
-{
-	// grid-stride on a few hundred workgroups: each ends with ONE add on `used` (a workgroup per 256 cells
-	// meant 4096 same-address atomics for the 2^20-cell uniform grid, 0.04 ms)
-	u32 mine = 0;
-	const u32 W = d_wide_count(wb);
-	for (u32 c = blockIdx.x * BUILD_THREADS + threadIdx.x; c < C; c += gridDim.x * BUILD_THREADS) {
-		u32 sp = span_io[c] - cstart[c]; // span_io holds the run end on entry
-		if (W && d_cell_active(wb, c))
-			sp += W;
-		span_io[c] = sp;
-		mine += sp != 0u ? 1u : 0u;
-	}
+// The cells' spans are formed INSIDE the scan that turns them into offsets (ugrt_scan.h: a load functor instead of
+// a kernel of its own): span = run end - run start (+ the wide triangles of an active cell), written back for the
+// tracers, the occupied cells counted with one atomic per tile of 4096 cells.
+struct SpanLoad {
+	const u32 *cstart;
+	u32 *span_io; // holds the run ends on entry
+	u32 *used;
+	WideBox wb;
+	__device__ __forceinline__ void operator()(u32 base, u32 n, u32 (&v)[SC_ITEMS]) const
+	{
+		__shared__ u32 s_used[SC_WAVES];
+		const u32 W = d_wide_count(wb);
+		u32 mine = 0;
 #pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-		mine += (u32)__shfl_xor((int)mine, m);
-	__shared__ u32 s_cnt[BUILD_THREADS / 64];
-	if ((threadIdx.x & 63) == 0)
-		s_cnt[threadIdx.x >> 6] = mine;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		u32 tot = 0;
-		for (int w = 0; w < BUILD_THREADS / 64; w++)
-			tot += s_cnt[w];
-		if (tot)
-			atomicAdd(used, tot);
+		for (int i = 0; i < SC_ITEMS; i++) {
+			const u32 c = base + (u32)i;
+			u32 sp = 0;
+			if (c < n) {
+				sp = span_io[c] - cstart[c];
+				if (W && d_cell_active(wb, c))
+					sp += W;
+				span_io[c] = sp;
+				mine += sp != 0u ? 1u : 0u;
+			}
+			v[i] = sp;
+		}
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1)
+			mine += (u32)__shfl_xor((int)mine, m);
+		if ((threadIdx.x & 63u) == 0u)
+			s_used[threadIdx.x >> 6] = mine;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			u32 tot = 0;
+			for (int w = 0; w < SC_WAVES; w++)
+				tot += s_used[w];
+			if (tot)
+				atomicAdd(used, tot);
+		}
 	}
-}
+};
+// what the last tile of that scan does: the tail of an asynchronous build's report (cells used, the status word at
+// its end) and the wide-triangle counter back to zero for the next build of this grid
+struct SpanTail {
+	static constexpr bool active = true;
+	u32 *report_tail;       // nullptr: no report
+	const u32 *used, *status;
+	u32 *zero;              // nullptr: nothing to clear
+	__device__ __forceinline__ void operator()() const
+	{
+		if (report_tail) {
+			report_tail[0] = __hip_atomic_load(used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			report_tail[1] = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (zero)
+			*zero = 0u;
+	}
+};
 
 // ascending order of the (few) wide triangle ids: rank = number of smaller ids
 __global__ __launch_bounds__(BUILD_THREADS) void k_wide_rank(const u32 *__restrict__ wl, u32 W,
@@ -641,13 +671,6 @@ static int bits_for(u32 C)
 // written out of bounds) and a status bit is raised, which the host sees at its next synchronisation
 // (UGRT_EOVERFLOW; the following build of the grid runs synchronously and sizes the buffers exactly).
 // ---------------------------------------------------------------------------
-// the tail of an asynchronous build's report when no merge kernel runs (see k_merge_wide)
-__global__ void k_report_tail(u32 *__restrict__ report_tail, const u32 *__restrict__ used, const u32 *__restrict__ status)
-{
-	report_tail[0] = *used;
-	report_tail[1] = *status;
-}
-
 static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, int ylo, int yhi)
 {
 	hipStream_t st = ctx->stream;
@@ -737,14 +760,15 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	u32 *cstart = (u32 *)G.span.p + C, *used = cstart + C;
 	hipLaunchKernelGGL(k_bounds, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, 0u, cstart, (u32 *)G.span.p,
 			   (const u32 *)rw);
-	const u32 span_blocks = (C + BUILD_THREADS - 1) / BUILD_THREADS;
-	hipLaunchKernelGGL(k_span, dim3(span_blocks < 512u ? span_blocks : 512u), dim3(BUILD_THREADS), 0, st,
-			   (const u32 *)cstart, (u32 *)G.span.p, C, used, wb);
-	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C)))
-		return rc;
+	// spans + offsets in one kernel; a grid without wide triangles ends its report there (with them: k_merge_wide)
+	{
+		SpanLoad sl = { (const u32 *)cstart, (u32 *)G.span.p, used, wb };
+		SpanTail tl = { no_wide ? report + 2 : (u32 *)nullptr, (const u32 *)used, (const u32 *)status, wide_counter(G, F) };
+		if ((rc = ugrt_scan_launch<false>(ctx, sl, (u32 *)G.offset.p, (size_t)C, tl)))
+			return rc;
+		G.wide_zeroed = wide_counter(G, F);
+	}
 	if (no_wide) {
-		hipLaunchKernelGGL(k_report_tail, dim3(1), dim3(1), 0, st, report + 2, (const u32 *)used, (const u32 *)status);
 		G.keys = k1;
 		G.vals = v1;
 	} else {
@@ -879,14 +903,15 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 					   st, (const u32 *)k1, Rn, cstart, (u32 *)G.span.p, (const u32 *)nullptr);
 			UGRT_HIP(hipGetLastError());
 		}
-		const u32 span_blocks = (C + BUILD_THREADS - 1) / BUILD_THREADS;
-		hipLaunchKernelGGL(k_span, dim3(span_blocks < 512u ? span_blocks : 512u), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)cstart, (u32 *)G.span.p, C, used, wb);
-		UGRT_HIP(hipGetLastError());
 	}
-	rc = ugrt_prim_exclusive_scan(ctx, (const u32 *)G.span.p, (u32 *)G.offset.p, (size_t)C);
-	if (rc)
-		return rc;
+	{
+		// spans + offsets in one kernel (an empty build: the cleared words are the spans)
+		SpanLoad sl = { (const u32 *)cstart, (u32 *)G.span.p, used, wb };
+		SpanTail tl = { (u32 *)nullptr, (const u32 *)used, (const u32 *)nullptr, wide_counter(G, F) };
+		if ((rc = ugrt_scan_launch<false>(ctx, sl, (u32 *)G.offset.p, (size_t)C, tl)))
+			return rc;
+		G.wide_zeroed = wide_counter(G, F);
+	}
 	if (W) {
 		if (Rn) {
 			hipLaunchKernelGGL(k_merge_narrow, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS),
@@ -933,10 +958,13 @@ static int build_prologue(ugrt_ctx *ctx, Grid &G, const int *d_facelist, const f
 	// unless the caller vouches for it (UGRT_FLAG_STATIC_GEOMETRY) and these are the arrays last seen
 	if ((ctx->cfg.flags & UGRT_FLAG_STATIC_GEOMETRY) && ctx->rec_valid && ctx->rec_verts == d_vertlist &&
 	    ctx->rec_tris == d_facelist && ctx->rec_faces == F) {
-		UGRT_HIP(hipMemsetAsync(wide_counter(G, F), 0, 4, ctx->stream));
+		if (G.wide_zeroed != wide_counter(G, F)) // (the last build of this grid left it at zero: SpanTail)
+			UGRT_HIP(hipMemsetAsync(wide_counter(G, F), 0, 4, ctx->stream));
+		G.wide_zeroed = nullptr; // the count kernel dirties it; the build's last scan clears it again
 		return UGRT_OK;
 	}
 	ctx->rec_valid = false;
+	G.wide_zeroed = nullptr;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->trirec, (size_t)F * 48)))
 		return rc;
 	hipLaunchKernelGGL(k_tri_records, dim3((F + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,

@@ -68,6 +68,7 @@ struct Grid {
 	int dims[3] = { 0, 0, 0 };
 	float ug[12] = { 0 }; // uniform grid: lo[3], cell[3], inv cell[3]
 	bool valid = false;
+	const u32 *wide_zeroed = nullptr; // the wide-triangle counter the last build's scan left at zero (build_prologue)
 };
 
 // layout of ugrt_ctx::d_small (u32 words of device scratch)

@@ -49,9 +49,23 @@ __device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long 
 __global__ __launch_bounds__(256) void k_dda_prepare(const int *__restrict__ active, int p0, int npix, int W,
 						      float *__restrict__ hit_t, int *__restrict__ hit_id,
 						      u32 *__restrict__ list, u32 *__restrict__ count,
-						      u32 *__restrict__ ticket)
+						      u32 *__restrict__ ticket, u32 pix_blocks, const u32 *__restrict__ span, u32 C,
+						      u32 *__restrict__ bitmap)
 {
 	const int lane = threadIdx.x & 63;
+	if (blockIdx.x >= pix_blocks) {
+		// the workgroups behind the pixels' write the window kernel's occupancy bitmap: bit c = span[c] != 0, one
+		// 64-bit word per wave and 64 cells
+		for (u32 base = ((blockIdx.x - pix_blocks) * 4u + (threadIdx.x >> 6)) * 64u; base < C; base += (gridDim.x - pix_blocks) * 256u) {
+			const u32 c = base + (u32)lane;
+			const unsigned long long m = __ballot(c < C && span[c] != 0u);
+			if (lane == 0) {
+				bitmap[base >> 5] = (u32)m;
+				bitmap[(base >> 5) + 1u] = (u32)(m >> 32);
+			}
+		}
+		return;
+	}
 	const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * DDA_PREP_SPAN;
 	if (blockIdx.x == 0 && threadIdx.x == 0)
 		*ticket = 0; // the tracer's waves draw their ray groups from it
@@ -718,9 +732,16 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	if (!counting)
 		ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipMemsetAsync(dcount, 0, 4, ctx->stream));
-	hipLaunchKernelGGL(k_dda_prepare, dim3((ctx->npix + 4 * DDA_PREP_SPAN - 1) / (4 * DDA_PREP_SPAN)), dim3(256), 0,
-			   ctx->stream, d_active, ctx->p0, ctx->npix, ctx->cfg.width, d_hit_t, d_hit_id, list, dcount,
-			   ctx->d_small + UGRT_DSMALL_TICKET);
+	// (the window kernel's occupancy bitmap is written by extra workgroups of the same launch)
+	const bool walk = ctx->opt[UGRT_OPT_DDA_KERNEL] <= 0;
+	const u32 ncell_all = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
+	if (walk && (rc = ugrt_buf_reserve(ctx, ctx->ubitmap, ((size_t)ncell_all + 63) / 64 * 8 + 8)))
+		return rc;
+	const u32 pix_blocks = (u32)((ctx->npix + 4 * DDA_PREP_SPAN - 1) / (4 * DDA_PREP_SPAN));
+	const u32 bm_blocks = walk ? ((ncell_all + 255u) / 256u < 1024u ? (ncell_all + 255u) / 256u : 1024u) : 0u;
+	hipLaunchKernelGGL(k_dda_prepare, dim3(pix_blocks + bm_blocks), dim3(256), 0, ctx->stream, d_active, ctx->p0, ctx->npix,
+			   ctx->cfg.width, d_hit_t, d_hit_id, list, dcount, ctx->d_small + UGRT_DSMALL_TICKET, pix_blocks, d_span,
+			   ncell_all, (u32 *)ctx->ubitmap.p);
 	if (!counting) {
 		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 		ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
@@ -760,9 +781,6 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	}
 	if (kernel == 0) {
 		// window kernel (ugrt_dda_walk.hip)
-		const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
-		if ((rc = ugrt_buf_reserve(ctx, ctx->ubitmap, ((size_t)ncell + 63) / 64 * 8 + 8)))
-			return rc;
 		if (counting)
 			UGRT_HIP(hipMemsetAsync(dc, 0, DS_END * sizeof(unsigned long long), ctx->stream));
 		if ((rc = ugrt_dda_walk_launch(ctx, g, d_value_list, d_span, d_offset, (u32 *)ctx->ubitmap.p, d_vertlist, d_trilist, rec,

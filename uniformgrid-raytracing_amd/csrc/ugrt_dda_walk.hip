@@ -35,21 +35,6 @@ enum { WS_WINDOWS = 3, WS_JOBS, WS_JOB_RAYS, WS_CULL_BATCHES, WS_CULL_TESTS, WS_
        WS_END = WS_PHASE_HEAVY + 12 };
 static_assert(WS_END <= 3 + UGRT_DDA_STATS, "window kernel statistics");
 
-// occupancy bitmap: bit c of the word array = span[c] != 0 (a wave writes one 64-bit word per 64 cells)
-__global__ __launch_bounds__(256) void k_cell_bitmap(const u32 *__restrict__ span, u32 C, u32 *__restrict__ bitmap)
-{
-	const u32 lane = threadIdx.x & 63u;
-	for (u32 base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; base < C; base += gridDim.x * 256u) {
-		const u32 c = base + lane;
-		const bool ne = c < C && span[c] != 0u;
-		const unsigned long long m = __ballot(ne);
-		if (lane == 0u) {
-			bitmap[base >> 5] = (u32)m;
-			bitmap[(base >> 5) + 1u] = (u32)(m >> 32);
-		}
-	}
-}
-
 // key of the optional ray sort (SURVEY 8f.2 as written: entry cell, then direction octant)
 __global__ __launch_bounds__(256) void k_dda_sort_keys(DGrid g, const float *__restrict__ rays, const u32 *__restrict__ list,
 						       const u32 *__restrict__ count_p, u32 cap, u32 *__restrict__ keys)
@@ -586,16 +571,12 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 	} // groups
 }
 
-// launched by ugrt_trace_dda (ugrt_dda.hip) behind k_dda_prepare; `bitmap` has (ncell + 63) / 64 * 2 words
+// launched by ugrt_trace_dda (ugrt_dda.hip) behind k_dda_prepare, which also wrote `bitmap` ((ncell + 63) / 64 * 2 words)
 int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
 			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
 			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
 			 bool counting, u32 RPW, u32 CULL_MIN, u32 CULL_WORK, int blocks)
 {
-	const u32 ncell = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
-	const u32 bblocks = (ncell + 255u) / 256u;
-	hipLaunchKernelGGL(k_cell_bitmap, dim3(bblocks < 2048u ? bblocks : 2048u), dim3(256), 0, ctx->stream, d_span, ncell, bitmap);
-	UGRT_HIP(hipGetLastError());
 	u32 *ticket = ctx->d_small + UGRT_DSMALL_TICKET;
 #define WK_LAUNCH(CNTV, RECV)                                                                                          \
 	hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \

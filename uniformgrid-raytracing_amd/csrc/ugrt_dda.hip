@@ -749,7 +749,9 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	UGRT_HIP(hipGetLastError());
 	// launch shape (ugrt_ctx_set_option; no effect on results): which kernel, rays per wave, list length from
 	// which a lone ray's cell is tested by the whole wave, list length from which a shared cell is culled first
-	const int kernel = ctx->opt[UGRT_OPT_DDA_KERNEL] > 0 ? ctx->opt[UGRT_OPT_DDA_KERNEL] : 0; // 0 window, 1 per-ray, 2 beam
+	// 0 window, 1 per-ray, 2 beam (the window kernel packs the steps left per axis into 10 bits each: ugrt_ctx_create
+	// admits at most 1024 cells per axis)
+	const int kernel = ctx->opt[UGRT_OPT_DDA_KERNEL] > 0 ? ctx->opt[UGRT_OPT_DDA_KERNEL] : 0;
 	const bool beam = kernel != 1;
 	u32 DDA_RPW = ctx->opt[UGRT_OPT_DDA_RPW] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_RPW] : (kernel == 2 ? 64u : 32u);
 	const u32 DDA_COOP = ctx->opt[UGRT_OPT_DDA_COOP] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_COOP] : 8u;

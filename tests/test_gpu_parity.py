@@ -497,13 +497,15 @@ def test_radix_sort_is_the_stable_sort(ugrt, torch, n, bits, kind):
     dk, dv = ctx.upload(keys.view(np.int32)), ctx.upload(vals.view(np.int32))
     mask = np.uint32((1 << bits) - 1) if bits < 32 else np.uint32(0xFFFFFFFF)
     order = np.argsort(keys & mask, kind="stable")
-    for library in (False, True):
-        ok, ov = torch.empty_like(dk), torch.empty_like(dv)
-        ctx.sort_pairs(dk, ok, dv, ov, bits, library=library)
-        ctx.synchronize()
-        np.testing.assert_array_equal(u32(ok), keys[order])
-        np.testing.assert_array_equal(u32(ov), vals[order])
-        np.testing.assert_array_equal(u32(dk), keys)  # inputs untouched
+    for library, items in ((False, -1), (False, 8), (False, 16), (True, -1)):  # items: pairs per thread of a pass
+        ctx.set_option("sort_items", items)
+        for rep in range(2):  # twice: the sort's state (tickets, histogram rows) must be clean again after a sort
+            ok, ov = torch.empty_like(dk), torch.empty_like(dv)
+            ctx.sort_pairs(dk, ok, dv, ov, bits, library=library)
+            ctx.synchronize()
+            np.testing.assert_array_equal(u32(ok), keys[order])
+            np.testing.assert_array_equal(u32(ov), vals[order])
+            np.testing.assert_array_equal(u32(dk), keys)  # inputs untouched
 
 
 def test_known_answers_on_gpu(ugrt, torch):

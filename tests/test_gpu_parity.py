@@ -246,6 +246,75 @@ def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
         assert_bits_equal(cr.hit_t.cpu().numpy(), want["hit_t"], "counting kernel %d" % k)
 
 
+@pytest.mark.parametrize("name,ud,seed", [("crash", (32, 32, 16), 1), ("crash", (7, 64, 3), 2), ("hall", (16, 16, 8), 3),
+                                          ("cornell", (5, 5, 5), 4)])
+def test_bounce_kernels_on_synthetic_rays(ugrt, O, torch, name, ud, seed):
+    """The bounce kernels fed rays no camera pass produces: origins inside, on the boundary of and far outside the
+    grid, directions with zero components (axis-parallel rays), negative zeros, rays along cell boundaries and
+    diagonals, rays that miss the grid, all mixed within a wave.  Hit ids equal and t bit-equal to the CPU
+    restatement for every kernel, and the counting variant's work counts too."""
+    s = scene(ugrt, name)
+    W, H, lg = 256, 128, (32, 32)
+    N = W * H
+    ctx, r = make(ugrt, s, W, H, lg, udims=ud)
+    setup = setup_for(ugrt, s, "ref" if name != "cornell" else "B")
+    r.display(setup, shadows=False, reflect=True)  # builds the uniform grid (and allocates the ray buffers)
+    ctx.synchronize()
+    rng = np.random.default_rng(seed)
+    v3 = np.asarray(s["verts"], np.float32).reshape(-1, 3)
+    lo, hi = v3.min(0), v3.max(0)
+    ext = hi - lo
+    rays = np.zeros((N, 6), np.float32)
+    kind = rng.integers(0, 8, N)
+    o = lo + rng.random((N, 3)) * ext                                   # inside
+    far = lo - ext * 2 + rng.random((N, 3)) * ext * 5                  # anywhere around
+    o = np.where((kind == 1)[:, None], far, o)
+    cs = ext / np.asarray(ud, np.float32)
+    snapped = lo + np.round((o - lo) / cs) * cs                         # on cell boundaries
+    o = np.where((kind == 2)[:, None], snapped, o)
+    d = rng.normal(size=(N, 3))
+    axis = rng.integers(0, 3, N)
+    ax_d = np.zeros((N, 3)); ax_d[np.arange(N), axis] = rng.choice([-1.0, 1.0], N)
+    d = np.where((kind == 3)[:, None], ax_d, d)                         # axis-parallel
+    plane = d.copy(); plane[np.arange(N), axis] = 0.0
+    d = np.where((kind == 4)[:, None], plane, d)                        # one zero component
+    d = np.where((kind == 5)[:, None], np.sign(d) * np.array([1.0, 1.0, 1.0]), d)  # exact diagonals
+    d = np.where((kind == 6)[:, None], d * 1e-3, d)                     # short direction vectors (not normalised)
+    nz = np.linalg.norm(d, axis=1) == 0
+    d[nz] = (1.0, 0.0, 0.0)
+    rays[:, :3], rays[:, 3:] = o, d
+    negz = (kind == 7)
+    rays[negz, 3 + axis[negz]] = -0.0                                   # negative zero on one axis
+    active = (rng.random(N) < 0.7).astype(np.int32)
+    ug = O.grid_uniform(s["faces"], s["verts"], lo, hi, ud)
+    want_t, want_id, want_cnt = O.trace_dda(ug, s["verts"], s["faces"], rays.reshape(-1), active, 0, N, N)
+    r.rays.copy_(torch.from_numpy(rays.reshape(-1)).to(r.rays.device))
+    r.active.copy_(torch.from_numpy(active).to(r.active.device))
+    uvalue, uspan, uoffset, _ = ctx.grid_ptrs(ugrt.GRID_UNIFORM)
+    for opts in (dict(dda_kernel=0), dict(dda_kernel=0, dda_rays_per_wave=64), dict(dda_kernel=0, dda_cull_work=1, dda_cull_min=1),
+                 dict(dda_kernel=0, dda_sort=1), dict(dda_kernel=1), dict(dda_kernel=2)):
+        for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_cull_work", "dda_sort"):
+            ctx.set_option(k, opts.get(k, -1))
+        r.hit_t.fill_(7.0)
+        r.hit_id.fill_(7)
+        ctx.trace_dda(uvalue, uspan, uoffset, r.d_verts, r.d_faces, r.rays, r.active, r.hit_t, r.hit_id)
+        ctx.synchronize()
+        np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want_id, err_msg=str(opts))
+        assert_bits_equal(r.hit_t.cpu().numpy(), want_t, "dda t %r" % (opts,))
+    assert (want_id >= 0).sum() > 200 and (want_id[active == 1] < 0).sum() > 200
+    cctx, cr = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_COUNT_WORK, udims=ud)
+    cr.display(setup, shadows=False, reflect=True)
+    cctx.synchronize()
+    cr.rays.copy_(r.rays)
+    cr.active.copy_(r.active)
+    cv, csn, co, _ = cctx.grid_ptrs(ugrt.GRID_UNIFORM)
+    for k in (0, 2):
+        cctx.set_option("dda_kernel", k)
+        cctx.trace_dda(cv, csn, co, cr.d_verts, cr.d_faces, cr.rays, cr.active, cr.hit_t, cr.hit_id)
+        st = cctx.stats()
+        assert [int(st[3]), int(st[4]), int(st[5])] == want_cnt, (k, st[3:6], want_cnt)
+
+
 def test_animation(ugrt, O, torch):
     """copy_data_transform (transformation_kernel.cu:4) then a rebuilt frame."""
     s = scene(ugrt, "crash")

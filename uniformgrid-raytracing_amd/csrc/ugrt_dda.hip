@@ -788,7 +788,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		if ((rc = ugrt_dda_walk_launch(ctx, g, d_value_list, d_span, d_offset, (u32 *)ctx->ubitmap.p, d_vertlist, d_trilist, rec,
 					       d_rays, (const u32 *)list, (const u32 *)dcount, d_hit_t, d_hit_id,
 					       counting ? dc : (unsigned long long *)nullptr, counting, DDA_RPW, CULL_MIN,
-					       ctx->opt[UGRT_OPT_DDA_CULL_WORK] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_WORK] : 320u, blocks)))
+					       ctx->opt[UGRT_OPT_DDA_CULL_WORK] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_WORK] : 10u * DDA_RPW, blocks)))
 			return rc;
 		if (counting) {
 			unsigned long long h[DS_END];

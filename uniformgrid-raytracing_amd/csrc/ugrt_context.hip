@@ -141,7 +141,6 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->rs_tmp[1]);
 	buf_free(ctx->trirec);
 	buf_free(ctx->witems);
-	buf_free(ctx->wcount);
 	buf_free(ctx->wscan);
 	buf_free(ctx->ubitmap);
 	buf_free(ctx->scan_state);
@@ -150,7 +149,6 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->rmap[0]);
 	buf_free(ctx->rmap[1]);
 	buf_free(ctx->rstart);
-	buf_free(ctx->cchunks);
 	buf_free(ctx->cbase);
 	buf_free(ctx->skey[0]);
 	buf_free(ctx->skey[1]);
@@ -158,7 +156,6 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 	buf_free(ctx->sval[1]);
 	buf_free(ctx->sdesc);
 	buf_free(ctx->sstart);
-	buf_free(ctx->scnt);
 	buf_free(ctx->sbase);
 	buf_free(ctx->tkey[0]);
 	buf_free(ctx->tkey[1]);

@@ -134,13 +134,13 @@ struct ugrt_ctx {
 	const int *rec_tris = nullptr;
 	int rec_faces = 0;
 	bool rec_valid = false;
-	DevBuf witems, wcount, wscan; // tracer work lists
+	DevBuf witems, wscan; // tracer work lists
 	DevBuf ubitmap;               // bounce: occupancy bitmap of the uniform grid's cells (1 bit per cell)
 	DevBuf dsort;                 // bounce, option dda_sort: keys + sorted keys + sorted list
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)
-	DevBuf rstart, cchunks, cbase; // ray runs per light cell (sort_rays)
-	DevBuf skey[2], sval[2], sdesc, sstart, scnt, sbase; // shadow tracer: re-grouped rays, beams, counts
+	DevBuf rstart, cbase; // ray runs per light cell (sort_rays)
+	DevBuf skey[2], sval[2], sdesc, sstart, sbase; // shadow tracer: re-grouped rays, beams, counts
 	DevBuf tkey[2], tval[2], tbcnt;                      // shadow tracer: candidate pairs, runs per beam
 	DevBuf sray;                                         // shadow tracer: rebuilt rays {direction, distance}, beam order
 	DevBuf citem;                                        // shadow tracer: the cull items (CullItem table)

@@ -1,6 +1,7 @@
 // ugrt_scan.h -- the prefix-sum kernel of ugrt_scan.hip as a template: LOAD produces a thread's 16 consecutive input
 // words (a plain array, or values computed on the fly: the grid builds form the cells' spans from the run bounds
-// inside the scan that turns them into offsets), TAIL runs once in the last tile to finish (the tail of an
+// inside the scan that turns them into offsets; the work lists' counts per cell or beam are formed the same way),
+// STORE may consume the sums where they are produced, TAIL runs once in the last tile to finish (the tail of an
 // asynchronous build's report).
 #ifndef UGRT_SCAN_H
 #define UGRT_SCAN_H
@@ -38,6 +39,12 @@ struct ScanTailNone {
 	static constexpr bool active = false;
 	__device__ __forceinline__ void operator()() const {}
 };
+// STORE (optional) sees a thread's 16 inputs beside their prefix sums, after `out` has been written: the kernel that
+// would turn counts and offsets into a list runs inside the scan
+struct ScanStoreNone {
+	static constexpr bool active = false;
+	__device__ __forceinline__ void operator()(u32, u32, const u32 (&)[16], const u32 (&)[16]) const {}
+};
 
 __device__ __forceinline__ u32 d_wave_incl_scan(u32 v, u32 lane)
 {
@@ -50,9 +57,9 @@ __device__ __forceinline__ u32 d_wave_incl_scan(u32 v, u32 lane)
 	return v;
 }
 
-template <bool INCLUSIVE, typename LOAD, typename TAIL>
+template <bool INCLUSIVE, typename LOAD, typename TAIL, typename STORE>
 __global__ __launch_bounds__(SC_THREADS) void k_scan_tiles(LOAD load, u32 *__restrict__ out, u32 n, unsigned long long *state,
-							    u32 *ctrl, u32 epoch, u32 vec, TAIL tail)
+							    u32 *ctrl, u32 epoch, u32 vec, TAIL tail, STORE store)
 {
 	__shared__ u32 s_tile, s_wave[SC_WAVES], s_prefix;
 	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -132,6 +139,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_tiles(LOAD load, u32 *__res
 			if (base + (u32)i < n)
 				out[base + i] = o[i];
 	}
+	if (STORE::active)
+		store(base, n, v, o);
 	// the last tile to get here leaves the ticket at zero for the next scan and runs the caller's epilogue.  What the
 	// epilogue reads from other tiles are device-scope atomics (performed in L2), so no cache has to be written back:
 	// it is enough that this thread's own earlier atomics have been acknowledged before it counts itself in
@@ -148,8 +157,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_tiles(LOAD load, u32 *__res
 }
 
 // enqueues the scan on ctx->stream; out must be 16-byte aligned for `vec_out`
-template <bool INCLUSIVE, typename LOAD, typename TAIL>
-static int ugrt_scan_launch(ugrt_ctx *ctx, const LOAD &load, u32 *out, size_t n, const TAIL &tail)
+template <bool INCLUSIVE, typename LOAD, typename TAIL, typename STORE = ScanStoreNone>
+static int ugrt_scan_launch(ugrt_ctx *ctx, const LOAD &load, u32 *out, size_t n, const TAIL &tail, const STORE &store = STORE())
 {
 	if (n == 0)
 		return UGRT_OK;
@@ -172,8 +181,8 @@ static int ugrt_scan_launch(ugrt_ctx *ctx, const LOAD &load, u32 *out, size_t n,
 	}
 	u32 *ctrl = (u32 *)ctx->scan_state.p;
 	unsigned long long *state = (unsigned long long *)((char *)ctx->scan_state.p + 64);
-	hipLaunchKernelGGL((k_scan_tiles<INCLUSIVE, LOAD, TAIL>), dim3(tiles), dim3(SC_THREADS), 0, st, load, out, (u32)n, state, ctrl,
-			   ctx->scan_epoch, vec, tail);
+	hipLaunchKernelGGL((k_scan_tiles<INCLUSIVE, LOAD, TAIL, STORE>), dim3(tiles), dim3(SC_THREADS), 0, st, load, out, (u32)n, state,
+			   ctrl, ctx->scan_epoch, vec, tail, store);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;
 }

@@ -1,6 +1,7 @@
 // ugrt_shade.hip -- per-pixel stages: light-space ray mapping, ray re-ordering,
 // shading, secondary-ray generation, vertex animation.
 #include "ugrt_dev.h"
+#include "ugrt_scan.h"
 
 #define PX_THREADS 256
 
@@ -74,18 +75,22 @@ __global__ __launch_bounds__(PX_THREADS) void k_ray_runs(const u32 *__restrict__
 		rend[k] = i + 1;
 }
 
-__global__ __launch_bounds__(PX_THREADS) void k_chunk_count(const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
-							     u32 ncell, u32 *__restrict__ cchunks)
-{
-	u32 c = blockIdx.x * PX_THREADS + threadIdx.x;
-	if (c >= ncell)
-		return;
-	cchunks[c] = (rend[c] - rstart[c] + 63u) / 64u;
-}
+// chunks per light cell, formed where the scan of the counts loads them (ugrt_scan.h)
+struct ChunkLoad {
+	const u32 *rstart, *rend;
+	__device__ __forceinline__ void operator()(u32 base, u32 n, u32 (&v)[SC_ITEMS]) const
+	{
+#pragma unroll
+		for (int k = 0; k < SC_ITEMS; k++) {
+			const u32 c = base + (u32)k;
+			v[k] = c < n ? (rend[c] - rstart[c] + 63u) / 64u : 0u;
+		}
+	}
+};
 
 // one thread per CHUNK (a cell with thousands of rays would otherwise serialise one thread)
 __global__ __launch_bounds__(PX_THREADS) void k_chunk_emit(const u32 *__restrict__ rstart,
-							    const u32 *__restrict__ cchunks,
+							    const u32 *__restrict__ rend,
 							    const u32 *__restrict__ incl, u32 ncell, u32 cap,
 							    u32 *__restrict__ prefix)
 {
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(PX_THREADS) void k_chunk_emit(const u32 *__restrict
 			lo = mid + 1;
 	}
 	const u32 c = lo;
-	const u32 j = k - (incl[c] - cchunks[c]);
+	const u32 j = k - (incl[c] - (rend[c] - rstart[c] + 63u) / 64u);
 	prefix[k] = rstart[c] + 64u * j;
 }
 
@@ -128,8 +133,6 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->rstart, (size_t)ncell * 8))) // run starts, then run ends
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->cchunks, (size_t)ncell * 4)))
-		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->cbase, (size_t)ncell * 4)))
 		return rc;
 	u32 *tmp = (u32 *)ctx->rmap[0].p;
@@ -154,18 +157,18 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 	hipLaunchKernelGGL(k_ray_runs, dim3((n + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
 			   (const u32 *)(d_map + n), n, rstart, rend);
 	UGRT_HIP(hipGetLastError());
-	hipLaunchKernelGGL(k_chunk_count, dim3((ncell + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
-			   (const u32 *)rstart, (const u32 *)rend, ncell, (u32 *)ctx->cchunks.p);
-	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_inclusive_scan(ctx, (const u32 *)ctx->cchunks.p, (u32 *)ctx->cbase.p, ncell)))
-		return rc;
+	{
+		const ChunkLoad load = { rstart, rend };
+		if ((rc = ugrt_scan_launch<true>(ctx, load, (u32 *)ctx->cbase.p, ncell, ScanTailNone())))
+			return rc;
+	}
 	{
 		// at most n/64 + ncell chunks exist; the kernel reads the exact count on the device
 		u32 maxchunks = n / 64u + ncell;
 		if (maxchunks > prefix_capacity)
 			maxchunks = prefix_capacity;
 		hipLaunchKernelGGL(k_chunk_emit, dim3((maxchunks + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
-				   (const u32 *)ctx->rstart.p, (const u32 *)ctx->cchunks.p, (const u32 *)ctx->cbase.p,
+				   (const u32 *)rstart, (const u32 *)rend, (const u32 *)ctx->cbase.p,
 				   ncell, prefix_capacity, d_prefix_map);
 	}
 	UGRT_HIP(hipGetLastError());

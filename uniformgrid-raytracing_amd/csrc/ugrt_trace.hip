@@ -18,6 +18,7 @@
 
 #include "ugrt_packet.h"
 #include "ugrt_rs_hist.h"
+#include "ugrt_scan.h"
 
 
 struct WItem {
@@ -30,39 +31,51 @@ struct WItem {
 // ---------------------------------------------------------------------------
 // work lists
 // ---------------------------------------------------------------------------
-// primary: one entry per cell of the band, x-major like the cell ids
-__global__ __launch_bounds__(WL_THREADS) void k_wl_count_primary(const u32 *__restrict__ span, int nby, int gy_lo,
-								  int rows, u32 ncell, u32 *__restrict__ cnt, u32 SEG)
-{
-	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (i >= ncell)
-		return;
-	u32 cell = (i / (u32)rows) * (u32)nby + (u32)gy_lo + (i % (u32)rows);
-	u32 sp = span[cell];
-	cnt[i] = sp ? (sp + SEG - 1) / SEG : 1u;
-}
-
-__global__ __launch_bounds__(WL_THREADS) void k_wl_fill_primary(const u32 *__restrict__ span,
-								 const u32 *__restrict__ offset, int nby, int gy_lo,
-								 int rows, u32 ncell, const u32 *__restrict__ cnt,
-								 const u32 *__restrict__ incl, WItem *__restrict__ items, u32 SEG)
-{
-	u32 i = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (i >= ncell)
-		return;
-	u32 cell = (i / (u32)rows) * (u32)nby + (u32)gy_lo + (i % (u32)rows);
-	u32 sp = span[cell], off = offset[cell], n = cnt[i];
-	u32 base = incl[i] - n;
-	for (u32 s = 0; s < n; s++) {
-		WItem w;
-		w.cell = cell;
-		w.begin = off + s * SEG;
-		u32 left = sp - s * SEG;
-		w.count = sp ? (left < SEG ? left : SEG) : 0u;
-		w.multi = n > 1;
-		items[base + s] = w;
+// primary: one entry per cell of the band, x-major like the cell ids.  The list is written by the scan of its
+// counts (ugrt_scan.h): the counts are formed where the scan loads them, the items where it has their positions
+struct WlPrimaryLoad {
+	const u32 *span;
+	u32 nby, gy_lo, rows, SEG;
+	__device__ __forceinline__ void operator()(u32 base, u32 n, u32 (&v)[SC_ITEMS]) const
+	{
+#pragma unroll
+		for (int k = 0; k < SC_ITEMS; k++) {
+			const u32 i = base + (u32)k;
+			u32 c = 0;
+			if (i < n) {
+				const u32 sp = span[(i / rows) * nby + gy_lo + (i % rows)];
+				c = sp ? (sp + SEG - 1) / SEG : 1u;
+			}
+			v[k] = c;
+		}
 	}
-}
+};
+struct WlPrimaryStore {
+	static constexpr bool active = true;
+	const u32 *span, *offset;
+	u32 nby, gy_lo, rows, SEG;
+	WItem *items;
+	__device__ __forceinline__ void operator()(u32 base, u32 n, const u32 (&v)[SC_ITEMS], const u32 (&incl)[SC_ITEMS]) const
+	{
+		for (int k = 0; k < SC_ITEMS; k++) {
+			const u32 i = base + (u32)k;
+			if (i >= n)
+				break;
+			const u32 cell = (i / rows) * nby + gy_lo + (i % rows);
+			const u32 sp = span[cell], off = offset[cell], cnt = v[k];
+			const u32 first = incl[k] - cnt;
+			for (u32 s = 0; s < cnt; s++) {
+				WItem w;
+				w.cell = cell;
+				w.begin = off + s * SEG;
+				const u32 left = sp - s * SEG;
+				w.count = sp ? (left < SEG ? left : SEG) : 0u;
+				w.multi = cnt > 1;
+				items[first + s] = w;
+			}
+		}
+	}
+};
 
 // ---------------------------------------------------------------------------
 // primary rays: rckernel_alpha, trace_kernel.cu:84-270 (NUM_SLABS = 1)
@@ -642,22 +655,19 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	u32 SEG = ctx->opt[UGRT_OPT_PRIMARY_SEG] > 0 ? (u32)ctx->opt[UGRT_OPT_PRIMARY_SEG] : 1024u;
 	SEG = SEG < 64u ? 64u : (SEG + 63u) / 64u * 64u;
 	const size_t cap = (size_t)ncell + R / SEG + 1;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->wcount, (size_t)ncell * 4)))
-		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)ncell * 4)))
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->witems, cap * sizeof(WItem))))
 		return rc;
-	u32 *cnt = (u32 *)ctx->wcount.p, *incl = (u32 *)ctx->wscan.p;
+	u32 *incl = (u32 *)ctx->wscan.p;
 	WItem *items = (WItem *)ctx->witems.p;
 	ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
-	hipLaunchKernelGGL(k_wl_count_primary, dim3((ncell + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   d_span, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt, SEG);
-	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_inclusive_scan(ctx, cnt, incl, ncell)))
-		return rc;
-	hipLaunchKernelGGL(k_wl_fill_primary, dim3((ncell + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   d_span, d_offset, ctx->nby, ctx->cfg.row_begin, rows, ncell, cnt, incl, items, SEG);
+	{
+		const WlPrimaryLoad load = { d_span, (u32)ctx->nby, (u32)ctx->cfg.row_begin, (u32)rows, SEG };
+		const WlPrimaryStore store = { d_span, d_offset, (u32)ctx->nby, (u32)ctx->cfg.row_begin, (u32)rows, SEG, items };
+		if ((rc = ugrt_scan_launch<true>(ctx, load, incl, ncell, ScanTailNone(), store)))
+			return rc;
+	}
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	PrimaryOut out = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
@@ -868,22 +878,29 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const K *__restrict_
 		rend[c] = i + 1;
 }
 
-// per light cell: number of beams, and number of cull items = triangle batches x beam chunks
-__global__ __launch_bounds__(WL_THREADS) void k_shadow_count(const u32 *__restrict__ span, const u32 *__restrict__ rstart,
-							      const u32 *__restrict__ rend, u32 C, u32 *__restrict__ gcnt,
-							      u32 *__restrict__ icnt, u32 beam,
-							      unsigned long long *__restrict__ tests)
-{
-	u32 c = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (c >= C)
-		return;
-	u32 g = (rend[c] - rstart[c] + beam - 1u) / beam;
-	u32 nb = (span[c] + 63u) / 64u;
-	gcnt[c] = g;
-	icnt[c] = nb * ((g + GCHUNK - 1) / GCHUNK);
-	if (g && span[c])
-		atomicAdd(tests, (unsigned long long)span[c] * (unsigned long long)g); // cells that matter are few
-}
+// per light cell: number of beams (ITEMS = false), or number of cull items = triangle batches x beam chunks -- formed
+// where the scans of these counts load them (ugrt_scan.h)
+template <bool ITEMS>
+struct ShadowCountLoad {
+	const u32 *span, *rstart, *rend;
+	u32 beam;
+	unsigned long long *tests;
+	__device__ __forceinline__ void operator()(u32 base, u32 C, u32 (&v)[SC_ITEMS]) const
+	{
+#pragma unroll
+		for (int k = 0; k < SC_ITEMS; k++) {
+			const u32 c = base + (u32)k;
+			u32 x = 0;
+			if (c < C) {
+				const u32 g = (rend[c] - rstart[c] + beam - 1u) / beam, sp = span[c];
+				x = ITEMS ? (sp + 63u) / 64u * ((g + GCHUNK - 1) / GCHUNK) : g;
+				if (!ITEMS && g && sp)
+					atomicAdd(tests, (unsigned long long)sp * (unsigned long long)g); // cells that matter are few
+			}
+			v[k] = x;
+		}
+	}
+};
 
 // smallest c with incl[c] > x (incl = inclusive scan over C cells, x < incl[C-1])
 __device__ __forceinline__ u32 d_find_cell(const u32 *__restrict__ incl, u32 C, u32 x)
@@ -1321,30 +1338,38 @@ __global__ void k_pair_check(const u32 *__restrict__ pcount, u32 cap, const u32 
 // an item with segment number XSEG_LAST takes all the remaining candidates of its beam (the segment is
 // the 8-bit sort key of the item list; XSEG_LAST + 1 marks the padding behind the last item)
 #define XSEG_LAST 254u
-__global__ __launch_bounds__(WL_THREADS) void k_pair_item_count(const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
-								 const GBox *__restrict__ boxes, u32 G, u32 *__restrict__ xcnt,
-								 unsigned long long *__restrict__ staged, u32 XSEG,
-								 const u32 *__restrict__ pg, u32 Gcap)
-{
-	u32 g = blockIdx.x * WL_THREADS + threadIdx.x;
-	unsigned long long mine = 0;
-	if (pg)
-		G = pg[0] ? pg[1] : 0u; // (no pairs: no items)
-	if (g < G) {
-		const u32 cand = pend[g] - pstart[g], nsub = (boxes[g].ray_count + 63u) / 64u;
-		const u32 nseg = (cand + XSEG - 1) / XSEG;
-		xcnt[g] = (nseg < XSEG_LAST + 1u ? nseg : XSEG_LAST + 1u) * nsub;
-		mine = (unsigned long long)cand * nsub;
-	} else if (g < Gcap) {
-		xcnt[g] = 0; // the scan runs over the capacity
-	}
-	// candidates staged by the exact pass (work accounting): one atomic per wave
+// items per beam, formed where the scan of the counts loads them (ugrt_scan.h; it runs over the capacity Gcap)
+struct PairItemLoad {
+	const u32 *pstart, *pend;
+	const GBox *boxes;
+	u32 G;
+	unsigned long long *staged;
+	u32 XSEG;
+	const u32 *pg;
+	__device__ __forceinline__ void operator()(u32 base, u32 Gcap, u32 (&v)[SC_ITEMS]) const
+	{
+		const u32 Gn = pg ? (pg[0] ? pg[1] : 0u) : G; // (no pairs: no items)
+		unsigned long long mine = 0;
 #pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-		mine += __shfl_xor(mine, m);
-	if ((threadIdx.x & 63) == 0 && mine)
-		atomicAdd(staged, mine);
-}
+		for (int k = 0; k < SC_ITEMS; k++) {
+			const u32 g = base + (u32)k;
+			u32 x = 0;
+			if (g < Gn && g < Gcap) {
+				const u32 cand = pend[g] - pstart[g], nsub = (boxes[g].ray_count + 63u) / 64u;
+				const u32 nseg = (cand + XSEG - 1) / XSEG;
+				x = (nseg < XSEG_LAST + 1u ? nseg : XSEG_LAST + 1u) * nsub;
+				mine += (unsigned long long)cand * nsub;
+			}
+			v[k] = x;
+		}
+		// candidates staged by the exact pass (work accounting): one atomic per wave
+#pragma unroll
+		for (int m = 32; m >= 1; m >>= 1)
+			mine += __shfl_xor(mine, m);
+		if ((threadIdx.x & 63) == 0 && mine)
+			atomicAdd(staged, mine);
+	}
+};
 
 // The exact-pass items, listed once (the tracer then starts with two loads instead of a 12-step search)
 // and ordered by SEGMENT first: all beams' first segments run before any second segment, so by the time a
@@ -1571,8 +1596,6 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	const size_t maxg = (size_t)n / 64 + C + 1; // beams
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sstart, (size_t)ncellk * 8))) // run starts, then run ends
 		return rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->scnt, (size_t)C * 8)))
-		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sbase, (size_t)C * 8)))
 		return rc;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sdesc, maxg * sizeof(GBox))))
@@ -1587,7 +1610,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	void *k0 = ctx->skey[0].p, *k1 = ctx->skey[1].p;
 	u32 *v0 = (u32 *)ctx->sval[0].p, *v1 = (u32 *)ctx->sval[1].p;
 	u32 *rstart = (u32 *)ctx->sstart.p, *rend = rstart + ncellk;
-	u32 *gcnt = (u32 *)ctx->scnt.p, *icnt = gcnt + C, *gincl = (u32 *)ctx->sbase.p, *iincl = gincl + C;
+	u32 *gincl = (u32 *)ctx->sbase.p, *iincl = gincl + C;
 	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = pstart + maxg;
 	GBox *boxes = (GBox *)ctx->sdesc.p;
 	unsigned long long *wcnt = (unsigned long long *)(ctx->d_small + UGRT_DSMALL_SHADOW_WORK); // [0] cull tests, [1] staged candidates
@@ -1643,13 +1666,14 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// work of a sub-group that stays lit
 	u32 XSEG = ctx->opt[UGRT_OPT_SHADOW_XSEG] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_XSEG] : 256u;
 	XSEG = XSEG < 64u ? 64u : (XSEG + 63u) / 64u * 64u;
-	hipLaunchKernelGGL(k_shadow_count, dim3((C + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st, d_span,
-			   (const u32 *)rstart, (const u32 *)rend, C, gcnt, icnt, beam, wcnt);
-	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_inclusive_scan(ctx, gcnt, gincl, C)))
-		return rc;
-	if ((rc = ugrt_prim_inclusive_scan(ctx, icnt, iincl, C)))
-		return rc;
+	{
+		const ShadowCountLoad<false> beams = { d_span, rstart, rend, beam, wcnt };
+		const ShadowCountLoad<true> items = { d_span, rstart, rend, beam, wcnt };
+		if ((rc = ugrt_scan_launch<true>(ctx, beams, gincl, C, ScanTailNone())))
+			return rc;
+		if ((rc = ugrt_scan_launch<true>(ctx, items, iincl, C, ScanTailNone())))
+			return rc;
+	}
 	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64 * BOX_WAVES), 0, st, ctx->cam,
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
 			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg + maxg * (beam / 64u)),
@@ -1787,12 +1811,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 				   pstart, pend, pgp);
 	}
 	UGRT_HIP(hipGetLastError());
-	u32 *xcnt = (u32 *)ctx->witems.p, *xincl = xcnt + Gcap;
-	hipLaunchKernelGGL(k_pair_item_count, dim3((Gcap + WL_THREADS - 1) / WL_THREADS), dim3(WL_THREADS), 0, st,
-			   (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, G, xcnt, wcnt + 1, XSEG, pgp, Gcap);
-	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_prim_inclusive_scan(ctx, xcnt, xincl, Gcap)))
-		return rc;
+	u32 *xincl = (u32 *)ctx->witems.p;
+	{
+		const PairItemLoad load = { pstart, pend, boxes, G, wcnt + 1, XSEG, pgp };
+		if ((rc = ugrt_scan_launch<true>(ctx, load, xincl, Gcap, ScanTailNone())))
+			return rc;
+	}
 	if ((rc = ugrt_buf_reserve(ctx, ctx->sitem, (size_t)xcap * 16)))
 		return rc;
 	u32 *iseg0 = (u32 *)ctx->sitem.p, *isub0 = iseg0 + xcap, *iseg1 = isub0 + xcap, *isub1 = iseg1 + xcap;

@@ -215,6 +215,11 @@ def main():
                     help="one stream: every stage after the other (default: light/uniform grid builds and the bounce "
                          "on a second stream beside the camera and shadow passes)")
     ap.add_argument("--repeats", type=int, default=4, help="extra untimed repetitions of the K steps (spread of the figure)")
+    ap.add_argument("--stream-order", default="A",
+                    help="order in which the renderers' streams are created (the runtime deals hardware queues in that order): "
+                         "A main0 side0 main1 side1 ...; B the main streams, then the side streams starting at frame 1; "
+                         "C mains, then sides from frame 0; D mains, then sides from frame F/2; or an explicit list "
+                         "such as s0,m1,s1,m2,s2,m3,s3 (x = a stream nothing runs on)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="independent frames in flight: F renderers (own contexts, buffers and streams) take the steps in "
                          "turn, so the GPU works on the tail of one frame and the head of the next (1 = a frame is "
@@ -307,13 +312,28 @@ def main():
     def make_renderers(rows):
         """One renderer per frame in flight for this rank's band `rows`, each with its own contexts and stream."""
         out = []
-        for i in range(max(1, args.frames_in_flight)):
-            stream = torch.cuda.Stream(device) if i else None
+        F = max(1, args.frames_in_flight)
+        # streams in the order they are created and first used; renderer 0's main stream is the default stream
+        if args.stream_order == "A":
+            roles = [(k, i) for i in range(F) for k in ("main", "side")][1:]
+        elif "," in args.stream_order:
+            roles = [({"m": "main", "s": "side", "x": "idle"}[w[0]], int(w[1:]) if len(w) > 1 else n)
+                     for n, w in enumerate(args.stream_order.split(","))]
+        else:
+            rot = {"B": 1, "C": 0, "D": F // 2}[args.stream_order]
+            roles = [("main", i) for i in range(1, F)] + [("side", (i + rot) % F) for i in range(F)]
+        made = {}
+        for role in roles:
+            made[role] = torch.cuda.Stream(device)
+            with torch.cuda.stream(made[role]):
+                torch.zeros(1, device=device)
+        for i in range(F):
+            stream = made[("main", i)] if i else None
             with torch.cuda.stream(stream):
                 cx = ugrt.Context(W, H, device=local, light_grid=lg, rows=rows, flags=flags, uniform_dims=udims)
                 rr = ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
                                    overlap=not args.no_overlap and shards is None, shards=shards,
-                                   helper_thread=args.waiting_builds)
+                                   helper_thread=args.waiting_builds, aux_stream=made[("side", i)])
             if stream is not None:
                 rr._stream = stream
             # the bounce's persistent waves: with several frames in flight every ray group gets a wave of its own (the

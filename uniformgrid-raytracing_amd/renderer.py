@@ -44,7 +44,7 @@ def make_camera(params, fovy, aspect):
 
 class Renderer:
     def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False,
-                 shards=None, helper_thread=True):
+                 shards=None, helper_thread=True, aux_stream=None):
         """overlap=True: the light grid and the uniform grid (which do not depend on the camera pass) are built
         by a second context on a second HIP stream while the main stream builds the perspective grid and
         traces the primary rays; streams are joined with events before the grids are consumed.  Same results.
@@ -62,7 +62,9 @@ class Renderer:
             from .device import Context
 
             self.main_stream = t.cuda.current_stream(ctx.device)
-            self.aux_stream = t.cuda.Stream(ctx.device)
+            # (aux_stream: a stream the caller made; which streams end up on the same hardware queue depends on
+            # the order in which they were created)
+            self.aux_stream = aux_stream if aux_stream is not None else t.cuda.Stream(ctx.device)
             with t.cuda.stream(self.aux_stream):
                 self.aux = Context(ctx.width, ctx.height, device=ctx.device_index, light_grid=ctx.light_grid,
                                    rows=ctx.rows, flags=int(ctx.cfg.flags),

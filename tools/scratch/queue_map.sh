@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-for o in A m1,s0,s1,m2,m3,s2,s3 s0,s1,s2,s3,m1,m2,m3; do
+for o in A; do
   tag=$(echo $o | tr -d ,)
   rocprofv3 --kernel-trace -d $PWD/gpurun_out/qmap_$tag -o t --output-format csv -- python3 bench.py --steps 6 --warmup 2 --cpu-seconds 0 --repeats 0 --no-verify --stream-order $o > gpurun_out/qmap_$tag.json 2> gpurun_out/qmap_$tag.err || { tail -5 gpurun_out/qmap_$tag.err; exit 1; }
   python3 - $PWD/gpurun_out/qmap_$tag <<'PY'

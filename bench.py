@@ -654,6 +654,16 @@ def main():
                          "which the factor is uncalibrated: read traffic as an UPPER bound (between FETCH_SIZE + WRITE_SIZE "
                          "and the figure given)",
                     traffic_is_upper_bound=True)
+    # (the other tracer with byte-exact algorithmic bytes, for the record: which of the two is the longer one changes
+    # with the workload and from round to round)
+    others = {}
+    for k in (("trace_primary", "trace_dda") if reflect else ("trace_primary",)):
+        if k != dom and k in stages and k in abytes:
+            ms = stages[k]["ms_per_launch"]
+            others[{"trace_primary": "k_trace_primary", "trace_dda": "k_trace_dda"}[k]] = dict(
+                achieved=round(abytes[k] / (ms * 1e-3) / 1e9, 2), frac=round(abytes[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                algorithmic_bytes_per_launch=int(abytes[k]), ms_per_launch=round(ms, 4))
+    roofline["other_kernels"] = others
     # whole-frame HBM figure: all kernels' PMC bytes of one frame over the frame time
     frame_hbm = None
     if tent and tent.get("frame_bytes"):

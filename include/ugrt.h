@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define UGRT_VERSION 102
+#define UGRT_VERSION 103
 
 enum {
 	UGRT_OK = 0,
@@ -189,7 +189,11 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * kernel 64); "dda_cull_min" / "dda_cull_work": a job's list is culled against its ray bundle first from this
  * many triangles / (triangles x rays) on; "dda_coop" (kernels 1 and 2) list length from which a lone ray's cell is
  * tested by the whole wave; "dda_sort" 1 = the bounce's ray list sorted by (entry cell, octant) instead of tile
- * order; "primary_seg" triangles per primary work item; "primary_order" 0 = a flush's jobs run in list order
+ * order; "dda_split" (window kernel) 1 = the ray groups that were long in the context's last bounce are cut into
+ * segments of their walk that run on different waves and are merged per ray (default; the history is kept per pixel,
+ * so it serves the next frame of a moving scene as far as it goes), 0 = off, 2..4 = every group is cut (tests);
+ * "dda_split_load" a group's jobs, in percent of the average group's, per segment it is cut into (default 400);
+ * "primary_seg" triangles per primary work item; "primary_order" 0 = a flush's jobs run in list order
  * (default: nearest triangles first), "primary_chunk" jobs between two looks at the rays' closest hits;
  * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64" shape the
  * shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix sort instead of the built-in

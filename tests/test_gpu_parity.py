@@ -222,8 +222,13 @@ def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
               dict(dda_kernel=0, dda_cull_work=64), dict(dda_kernel=0, dda_sort=1),
               dict(dda_kernel=0, dda_sort=1, dda_rays_per_wave=24), dict(dda_kernel=0, dda_blocks=7),
               dict(dda_kernel=1), dict(dda_kernel=2), dict(dda_kernel=2, dda_sort=1)]
+    # split walks (the long groups of the launch before cut into segments; dda_split >= 2: every group): launches in a
+    # row, so that each cuts by the history the one before it left
+    shapes += [dict(dda_kernel=0, dda_split=1, dda_split_load=50)] * 3 + [dict(dda_kernel=0, dda_split=k) for k in (2, 3, 4, 4)]
+    shapes += [dict(dda_kernel=0, dda_split=1, dda_split_load=50, dda_rays_per_wave=64)] * 3 + [dict(dda_kernel=0, dda_split=0)]
+    shapes += [dict(dda_kernel=0, dda_split=4, dda_blocks=3)] * 2  # (a cut group's segments wait for each other on no wave)
     for opts in shapes:
-        for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_cull_work", "dda_sort", "dda_blocks"):
+        for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_cull_work", "dda_sort", "dda_blocks", "dda_split", "dda_split_load"):
             ctx.set_option(k, opts.get(k, -1))
         r.hit_t.fill_(7.0)
         r.hit_id.fill_(7)
@@ -302,6 +307,34 @@ def test_bounce_kernels_on_synthetic_rays(ugrt, O, torch, name, ud, seed):
         np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want_id, err_msg=str(opts))
         assert_bits_equal(r.hit_t.cpu().numpy(), want_t, "dda t %r" % (opts,))
     assert (want_id >= 0).sum() > 200 and (want_id[active == 1] < 0).sum() > 200
+    # Split walks of the window kernel: the long ray groups of the LAST launch are cut into segments of windows that
+    # run on different waves and are merged per ray.  The same bits from every launch: the first one (no history), the
+    # ones that cut by the history (dda_split_load 50: every group above half the average), every group cut by force
+    # into two, three, four segments, a launch whose history is of OTHER rays, at 16 / 32 / 64 rays per wave.
+    for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_cull_work", "dda_sort"):
+        ctx.set_option(k, -1)
+    flipped = torch.from_numpy((1 - active).astype(np.int32)).to(r.active.device)
+    mine = r.active.clone()
+    for rpw in (32, 64, 16):
+        ctx.set_option("dda_rays_per_wave", rpw)
+        for split, load, other_rays_first in ((1, 50, False), (1, 50, False), (1, 50, False), (2, -1, False), (3, -1, False),
+                                              (4, -1, False), (4, -1, False), (1, 400, False), (1, 50, True), (4, -1, True), (0, -1, False)):
+            ctx.set_option("dda_split", split)
+            ctx.set_option("dda_split_load", load)
+            if other_rays_first:
+                r.active.copy_(flipped)
+                ctx.trace_dda(uvalue, uspan, uoffset, r.d_verts, r.d_faces, r.rays, r.active, r.hit_t, r.hit_id)
+                r.active.copy_(mine)
+            r.hit_t.fill_(7.0)
+            r.hit_id.fill_(7)
+            ctx.trace_dda(uvalue, uspan, uoffset, r.d_verts, r.d_faces, r.rays, r.active, r.hit_t, r.hit_id)
+            ctx.synchronize()
+            what = "rays per wave %d, dda_split %d, load %d, history of other rays %s" % (rpw, split, load, other_rays_first)
+            np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want_id, err_msg=what)
+            assert_bits_equal(r.hit_t.cpu().numpy(), want_t, "dda t, " + what)
+    ctx.set_option("dda_split", -1)
+    ctx.set_option("dda_split_load", -1)
+    ctx.set_option("dda_rays_per_wave", -1)
     cctx, cr = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_COUNT_WORK, udims=ud)
     cr.display(setup, shadows=False, reflect=True)
     cctx.synchronize()

@@ -42,17 +42,23 @@ run(ctx, r, 1)
 ref_t, ref_id = r.hit_t.clone(), r.hit_id.clone()
 ctx.set_option("dda_kernel", 0)
 res = {"rows": []}
-for rep in range(4):
+splits = [int(x) for x in sys.argv[sys.argv.index("--splits") + 1].split(",")] if "--splits" in sys.argv else [0, 1]
+loads = [int(x) for x in sys.argv[sys.argv.index("--loads") + 1].split(",")] if "--loads" in sys.argv else [200]
+for rep in range(3):
     for rpw in (32, 64):
         for blk in ((blocks,) if blocks else (1024, 3072)):
-            ctx.set_option("dda_rays_per_wave", rpw)
-            ctx.set_option("dda_blocks", blk)
-            r.hit_t.fill_(7.0)
-            r.hit_id.fill_(7)
-            ms = run(ctx, r)
-            same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
-            print("rpw %2d waves %4d: %.4f ms identical=%s" % (rpw, blk, ms, same), flush=True)
-            res["rows"].append({"rpw": rpw, "waves": blk, "ms": ms, "identical": same})
+            for split in splits:
+                for load in (loads if split == 1 else loads[:1]):
+                    ctx.set_option("dda_rays_per_wave", rpw)
+                    ctx.set_option("dda_blocks", blk)
+                    ctx.set_option("dda_split", split)
+                    ctx.set_option("dda_split_load", load)
+                    r.hit_t.fill_(7.0)
+                    r.hit_id.fill_(7)
+                    ms = run(ctx, r)
+                    same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
+                    print("rpw %2d waves %4d split %d load %4d: %.4f ms identical=%s" % (rpw, blk, split, load, ms, same), flush=True)
+                    res["rows"].append({"rpw": rpw, "waves": blk, "split": split, "load": load, "ms": ms, "identical": same})
 cctx, cr = make(ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_COUNT_WORK)
 cctx.set_option("dda_kernel", 0)
 for rpw in (32, 64):

@@ -1,6 +1,6 @@
 """A few launches of the DDA alone on the bench workload (for rocprofv3 --pmc / --kernel-trace).
 
-    python tools/dda_only.py KERNEL RPW [launches]      KERNEL 0 = beam, 1 = per-ray
+    python tools/dda_only.py KERNEL RPW [launches [dda_split]]      KERNEL 0 = window, 1 = per-ray, 2 = beam
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +13,8 @@ ctx = ugrt.Context(1920, 1080, light_grid=(128, 128), flags=ugrt.FLAG_SHADOW_ALL
 r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
 ctx.set_option("dda_kernel", kernel)
 ctx.set_option("dda_rays_per_wave", rpw)
+if len(sys.argv) > 4:
+    ctx.set_option("dda_split", int(sys.argv[4]))
 r.display(setup, reflect=True)
 ctx.synchronize()
 uvalue, uspan, uoffset, _ = ctx.grid_ptrs(ugrt.GRID_UNIFORM)

@@ -42,6 +42,8 @@ enum {
 	UGRT_OPT_PRIMARY_CHUNK,    // "primary_chunk": jobs between two looks at the rays' closest hits (4..64)
 	UGRT_OPT_SORT_ITEMS,       // "sort_items": pairs per thread of a radix pass, 16 (tiles of 8192) or 8 (4096)
 	UGRT_OPT_DDA_CULL_WORK,    // "dda_cull_work": window kernel: (triangles x rays) of a job from which its list is culled first
+	UGRT_OPT_DDA_SPLIT,        // "dda_split": window kernel: 0 = no split walks, 1 = long groups of the last launch cut into segments (default), 2..4 = every group (tests)
+	UGRT_OPT_DDA_SPLIT_LOAD,   // "dda_split_load": jobs of a group, in percent of the average group's, per segment it is cut into (default 400)
 	UGRT_OPT_COUNT
 };
 
@@ -137,6 +139,8 @@ struct ugrt_ctx {
 	DevBuf witems, wscan; // tracer work lists
 	DevBuf ubitmap;               // bounce: occupancy bitmap of the uniform grid's cells (1 bit per cell)
 	DevBuf dsort;                 // bounce, option dda_sort: keys + sorted keys + sorted list
+	DevBuf dsplit;                // bounce, split walks: work items, the groups' job history, merge state (ugrt_dda_walk.hip)
+	u32 dsplit_rpw = 0, dsplit_turn = 0; // rays per wave the history was laid out for; launches since
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)
 	DevBuf rstart, cbase; // ray runs per light cell (sort_rays)

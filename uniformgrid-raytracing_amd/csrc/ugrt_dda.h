@@ -10,6 +10,41 @@ struct DGrid {
 	int dims[3];
 };
 
+// Segments of the window kernel's long ray groups (ugrt_dda_walk.hip, "split walks"); all pointers null: no splitting
+#define WK_FBW 32      // windows of a group whose job counts are remembered (one byte each; later windows share the last)
+#define WK_MAXSEG 4    // segments a group is cut into at most
+struct WalkSplit {
+	u32 *hdr;                // this launch: [0] rays, [1] rays per wave, [2] segments listed in `items`, [3] jobs of the launch before
+	const uint2 *items;      // the cut groups' segments: x = group | segment << 24 | segments << 28, y = first window | end window << 16
+	const unsigned char *cut; // per group: listed in `items` (its turn among the whole groups is skipped)
+	unsigned char *fb;       // jobs of (group, window): written by this launch, read (and cleared) by the next one's k_dda_segments
+	const u32 *chunk;        // per 64 list entries: span of pixels * 8 + chunk of the span (what the groups' history is kept under)
+	u32 *walked_prev;        // per pixel: windows the ray walked in the launch before (which segments it is given to)
+	u32 *walked;             // the same of this launch (the smallest over the segments that saw the ray end)
+	u32 *done;               // per group: segments that have finished
+	unsigned long long *key; // per pixel: closest hit over the segments, t bits << 32 | segment << 29 | behind << 28 | list position; (a later segment's hit behind its cell: walk again)
+	u32 p0;                  // first pixel of the context's band: the per-pixel arrays below are indexed by pixel - p0
+	u32 *tend;               // per pixel: exit parameter of the ray's last cell (all ones until a segment sees the ray leave)
+	u32 *texam;              // per pixel: exit parameter of the last cell any segment has looked at for the ray (+inf: a segment stopped it)
+};
+
+// what the host passes to k_dda_segments beside WalkSplit (ugrt_dda_split_state)
+struct WalkSplitHost {
+	uint2 *items;
+	unsigned char *cut;
+	const u32 *hdr_prev;
+	u32 *hdr_next;
+	u32 load, force, maxg;
+};
+
+// what a group's history is kept under: the list is made of chunks of 64 entries that belong to one span of pixels
+// (k_dda_prepare), in an order that changes from launch to launch; `chunk` names every chunk's span and place in it
+__device__ __forceinline__ u32 d_group_key(const u32 *__restrict__ chunk, u32 g, u32 RPW)
+{
+	const u32 slot0 = g * RPW;
+	return chunk[slot0 >> 6] * (64u / RPW) + (slot0 & 63u) / RPW;
+}
+
 __device__ __forceinline__ int d_dcell(const DGrid &g, int k, float p)
 {
 	int c = ugrt_floor2i((p - g.lo[k]) * g.inv[k]);

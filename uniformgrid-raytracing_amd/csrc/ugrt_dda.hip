@@ -44,13 +44,16 @@ __device__ __forceinline__ unsigned long long d_wave_min_u64(unsigned long long 
 // consecutive entries are neighbours on the screen, i.e. rays that start next to each other and point the
 // same way (the order is irrelevant for the results).  Each wave owns DDA_PREP_SPAN / 64 consecutive tiles
 // and reserves its slots with ONE atomic (a counter bumped once per 64 pixels serialises ~30 k same-address
-// atomics, 0.08 ms at 1080p).
+// atomics, 0.08 ms at 1080p).  A span's entries are padded to whole chunks of 64 (entries ~0: no ray): the spans
+// land in the list in the order their atomics arrive, which changes from launch to launch, but a ray group (16, 32
+// or 64 consecutive entries) then always holds the same pixels, and `chunk` says which span and which of its chunks
+// every 64 entries are -- what the window kernel keeps the groups' history under (null: not wanted).
 #define DDA_PREP_SPAN 512
 __global__ __launch_bounds__(256) void k_dda_prepare(const int *__restrict__ active, int p0, int npix, int W,
 						      float *__restrict__ hit_t, int *__restrict__ hit_id,
 						      u32 *__restrict__ list, u32 *__restrict__ count,
 						      u32 *__restrict__ ticket, u32 pix_blocks, const u32 *__restrict__ span, u32 C,
-						      u32 *__restrict__ bitmap)
+						      u32 *__restrict__ bitmap, u32 *__restrict__ chunk)
 {
 	const int lane = threadIdx.x & 63;
 	if (blockIdx.x >= pix_blocks) {
@@ -95,10 +98,15 @@ __global__ __launch_bounds__(256) void k_dda_prepare(const int *__restrict__ act
 	}
 	if (total == 0)
 		return;
+	const u32 padded = (total + 63u) & ~63u;
 	u32 base = 0;
 	if (lane == 0)
-		base = atomicAdd(count, total);
+		base = atomicAdd(count, padded);
 	base = __shfl(base, 0);
+	if (chunk && (u32)lane < padded / 64u)
+		chunk[(base >> 6) + (u32)lane] = (u32)(first / DDA_PREP_SPAN) * (DDA_PREP_SPAN / 64) + (u32)lane;
+	if ((u32)lane < padded - total)
+		list[base + total + (u32)lane] = 0xFFFFFFFFu;
 #pragma unroll
 	for (int k = 0; k < DDA_PREP_SPAN / 64; k++) {
 		const bool a = (flags >> k) & 1ull;
@@ -132,8 +140,9 @@ __global__ __launch_bounds__(64) void k_trace_dda_ray(DGrid g, const u32 *__rest
 	// all 64 lanes still serve the cooperative rounds
 	for (u32 grp = blockIdx.x; grp * DDA_RPW < count; grp += gridDim.x) {
 	const u32 slot = grp * DDA_RPW + (u32)lane;
-	const bool inb = (u32)lane < DDA_RPW && slot < count;
+	bool inb = (u32)lane < DDA_RPW && slot < count;
 	const int p = inb ? (int)list[slot] : 0;
+	inb = inb && p != -1; // (padding: k_dda_prepare)
 	float res_t = -1.0f;
 	int res_id = -2;
 	u32 n_cells = 0, n_tests = 0;
@@ -355,8 +364,9 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_beam(DGrid g, const u32 *__
 		const unsigned long long clk0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 		unsigned long long tstamp = clk0, ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 		const u32 slot = grp * DDA_RPW + (u32)lane;
-		const bool inb = (u32)lane < DDA_RPW && slot < count;
+		bool inb = (u32)lane < DDA_RPW && slot < count;
 		const int p = inb ? (int)list[slot] : 0;
+		inb = inb && p != -1; // (padding: k_dda_prepare)
 		float res_t = -1.0f;
 		int res_id = -2;
 		u32 n_cells = 0, n_tests = 0;
@@ -699,7 +709,8 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_beam(DGrid g, const u32 *__
 int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
 			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
 			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
-			 bool counting, u32 RPW, u32 CULL_MIN, u32 CULL_WORK, int blocks);
+			 bool counting, u32 RPW, u32 CULL_MIN, u32 CULL_WORK, int blocks, const WalkSplit &sp, const WalkSplitHost &sph);
+int ugrt_dda_split_state(ugrt_ctx *ctx, u32 RPW, u32 total_refs, WalkSplit *sp, WalkSplitHost *sph);
 int ugrt_dda_sort_keys_launch(ugrt_ctx *ctx, const DGrid &g, const float *d_rays, const u32 *list, const u32 *dcount, u32 cap,
 			      u32 *keys);
 
@@ -739,14 +750,6 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		return rc;
 	const u32 pix_blocks = (u32)((ctx->npix + 4 * DDA_PREP_SPAN - 1) / (4 * DDA_PREP_SPAN));
 	const u32 bm_blocks = walk ? ((ncell_all + 255u) / 256u < 1024u ? (ncell_all + 255u) / 256u : 1024u) : 0u;
-	hipLaunchKernelGGL(k_dda_prepare, dim3(pix_blocks + bm_blocks), dim3(256), 0, ctx->stream, d_active, ctx->p0, ctx->npix,
-			   ctx->cfg.width, d_hit_t, d_hit_id, list, dcount, ctx->d_small + UGRT_DSMALL_TICKET, pix_blocks, d_span,
-			   ncell_all, (u32 *)ctx->ubitmap.p);
-	if (!counting) {
-		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
-		ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
-	}
-	UGRT_HIP(hipGetLastError());
 	// launch shape (ugrt_ctx_set_option; no effect on results): which kernel, rays per wave, list length from
 	// which a lone ray's cell is tested by the whole wave, list length from which a shared cell is culled first
 	// 0 window, 1 per-ray, 2 beam (the window kernel packs the steps left per axis into 10 bits each: ugrt_ctx_create
@@ -758,6 +761,22 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	const u32 CULL_MIN = ctx->opt[UGRT_OPT_DDA_CULL_MIN] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_MIN] : 8u;
 	if (DDA_RPW > 64u)
 		DDA_RPW = 64u;
+	// split walks of the window kernel (ugrt_dda_walk.hip): list positions go into 28 bits of their merge key, and the
+	// context's own grid tells how many there are
+	WalkSplit sp = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr };
+	WalkSplitHost sph = { nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+	if (kernel == 0 && !counting && ctx->opt[UGRT_OPT_DDA_SORT] != 1 &&
+	    (rc = ugrt_dda_split_state(ctx, DDA_RPW, d_span == (const unsigned *)G.span.p && d_offset == (const unsigned *)G.offset.p ? G.R : 0xFFFFFFFFu,
+				       &sp, &sph)))
+		return rc;
+	hipLaunchKernelGGL(k_dda_prepare, dim3(pix_blocks + bm_blocks), dim3(256), 0, ctx->stream, d_active, ctx->p0, ctx->npix,
+			   ctx->cfg.width, d_hit_t, d_hit_id, list, dcount, ctx->d_small + UGRT_DSMALL_TICKET, pix_blocks, d_span,
+			   ncell_all, (u32 *)ctx->ubitmap.p, (u32 *)sp.chunk);
+	if (!counting) {
+		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
+		ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);
+	}
+	UGRT_HIP(hipGetLastError());
 	// the launch is persistent (groups of rays are drawn from a ticket); "dda_blocks" caps its waves, which a context
 	// that runs beside another stream's kernels uses to leave registers and LDS of every CU to them
 	int blocks = launch_blocks_for((u32)ctx->npix / DDA_RPW + 1u);
@@ -788,7 +807,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		if ((rc = ugrt_dda_walk_launch(ctx, g, d_value_list, d_span, d_offset, (u32 *)ctx->ubitmap.p, d_vertlist, d_trilist, rec,
 					       d_rays, (const u32 *)list, (const u32 *)dcount, d_hit_t, d_hit_id,
 					       counting ? dc : (unsigned long long *)nullptr, counting, DDA_RPW, CULL_MIN,
-					       ctx->opt[UGRT_OPT_DDA_CULL_WORK] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_WORK] : 10u * DDA_RPW, blocks)))
+					       ctx->opt[UGRT_OPT_DDA_CULL_WORK] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_WORK] : 10u * DDA_RPW, blocks, sp, sph)))
 			return rc;
 		if (counting) {
 			unsigned long long h[DS_END];

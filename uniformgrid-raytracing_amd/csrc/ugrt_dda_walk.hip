@@ -24,7 +24,7 @@
 
 #define WK_AHEAD 8    // steps planned per window
 #define WK_MAXLAG 7   // phase alignment: a ray may wait this many steps for the rays behind it
-#define WK_JOBCAP 128 // jobs listed per pass (a step has at most 64: every pass lists at least one whole step)
+#define WK_JOBCAP 64  // jobs listed per pass: job j lives in lane j's registers (a step has at most 64 jobs)
 #define WK_NONE 0xFFFFFFFFu
 
 // statistics of the counting variant: counters[0..2] = tests, cells, rays (the algorithmic-byte formula), then
@@ -47,6 +47,10 @@ __global__ __launch_bounds__(256) void k_dda_sort_keys(DGrid g, const float *__r
 		return;
 	}
 	const u32 p = list[i];
+	if (p == 0xFFFFFFFFu) { // (the list's own padding: k_dda_prepare)
+		keys[i] = 0xFFFFFFFFu >> 8;
+		return;
+	}
 	float o[3], d[3], tenter = 0.0f;
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
@@ -99,6 +103,14 @@ __device__ __forceinline__ u32 d_mbit(m64 m) // m ? 1 : 0
 	asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
 	return r;
 }
+// v_writelane_b32: lane `l` of r := v (both wave-uniform); the other lanes keep theirs
+__device__ __forceinline__ u32 d_writelane(u32 r, u32 v, u32 l)
+{
+	// (one scalar operand beside m0: the constant bus; m0 is put back as it was found)
+	u32 keep;
+	asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(r), "=&s"(keep) : "s"(v), "s"(l));
+	return r;
+}
 // bit offset of the chosen axis' field in the packed step counters: axis 0 -> 0, 1 -> 10, 2 -> 20
 __device__ __forceinline__ u32 d_axis_shift(m64 a0, m64 a1)
 {
@@ -125,24 +137,41 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 							const float *__restrict__ rays, const u32 *__restrict__ list,
 							const u32 *__restrict__ count_p, float *__restrict__ hit_t,
 							int *__restrict__ hit_id, unsigned long long *__restrict__ counters,
-							u32 RPW, u32 CULL_MIN, u32 CULL_WORK, u32 *__restrict__ ticket)
+							u32 RPW, u32 CULL_MIN, u32 CULL_WORK, u32 *__restrict__ ticket, WalkSplit sp)
 {
 	__shared__ u32 s_cell[WK_AHEAD][64];    // cell of (step, ray); written for occupied cells only
 	__shared__ float s_tnext[WK_AHEAD][64]; // exit parameter of (step, ray); the entry of step q is the exit of q - 1
 	__shared__ __attribute__((aligned(16))) float s_surv[64 * TRI_STRIDE]; // survivors of a batch: 9 floats + list position
 	__shared__ __attribute__((aligned(16))) float s_ray[64 * 8];           // the group's rays {o, d}
 	__shared__ unsigned long long s_best[64];                            // per ray: closest hit of the running job
-	__shared__ u32 s_jcell[WK_JOBCAP], s_jbase[WK_JOBCAP], s_jlen[WK_JOBCAP];
-	__shared__ unsigned char s_jq[WK_JOBCAP];
 	__shared__ unsigned char s_rank[64]; // k-th ray of the running job
 	const int lane = threadIdx.x;
 	const u32 count = *count_p;
-	for (u32 grp = blockIdx.x; (unsigned long long)grp * RPW < count;) {
+	// work items: the ray groups, the long ones of the last launch cut into segments of windows (sp.items; "Split
+	// walks" below); without a list, item i is group i whole
+	const u32 ncut = sp.items ? sp.hdr[2] : 0u; // the cut groups' segments come first, then every group in turn
+	const u32 nitems = ncut + (u32)(((unsigned long long)count + RPW - 1u) / RPW);
+	m64 redo = 0ull; // rays of a cut group whose merged result has to be walked again in one piece
+	for (u32 it = blockIdx.x; it < nitems;) {
 		const unsigned long long clk0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 		unsigned long long tstamp = clk0, ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+		u32 grp = it - ncut, seg = 0u, nseg = 1u, wbeg = 0u, wend = 0xFFFFu;
+		if (it < ncut) {
+			const uint2 d = sp.items[it];
+			grp = d.x & 0xFFFFFFu;
+			if (redo == 0ull)
+				seg = (d.x >> 24) & 15u, nseg = d.x >> 28, wbeg = d.y & 0xFFFFu, wend = d.y >> 16;
+		} else if (sp.cut && sp.cut[grp]) { // (a cut group's turn as a whole group: nothing to do)
+			if (lane == 0)
+				it = gridDim.x + atomicAdd(ticket, 1u);
+			it = (u32)__builtin_amdgcn_readfirstlane((int)it);
+			continue;
+		}
 		const u32 slot = grp * RPW + (u32)lane;
-		const bool inb = (u32)lane < RPW && slot < count;
+		bool inb = (u32)lane < RPW && slot < count && (redo == 0ull || ((redo >> lane) & 1ull));
 		const int p = inb ? (int)list[slot] : 0;
+		inb = inb && p != -1; // (the list is padded to whole chunks of 64 entries per span of pixels: k_dda_prepare)
+		const u32 pb = (u32)p - sp.p0; // the ray's index in the split walks' per-pixel arrays
 		u32 n_cells = 0, n_tests = 0;
 		u32 st_win = 0, st_empty = 0, st_jobs = 0, st_jrays = 0, st_cb = 0, st_ct = 0, st_rounds = 0, st_pairs = 0;
 		// the walk's state: exit parameters per axis and their increments (the specification's tmax / tdelta), the
@@ -156,6 +185,10 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 		float best_t = 3.0e38f, tcur = 0.0f;
 		u32 best_ref = WK_NONE; // list position of the closest hit so far (value_list[best_ref] is its triangle)
 		bool walking = false, hitstop = false;
+		bool best_behind = false;               // (cut groups) the closest hit lies before the entry of the cell it was found in
+		float tend = __builtin_huge_valf();     // (cut groups) exit parameter of the last cell, once the ray has left the grid
+		u32 widx = 0u;                          // window number
+		u32 nwin = 0u;                          // windows this ray has walked
 		// set-up: exactly the arithmetic of the per-ray kernel and of the specification
 		{
 			float o[3] = { 0, 0, 0 }, d[3] = { 0, 0, 0 };
@@ -218,6 +251,8 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			*reinterpret_cast<float2 *>(&s_ray[lane * 8 + 4]) = make_float2(d[1], d[2]);
 			s_best[lane] = ~0ull;
 		}
+		if (inb && !walking)
+			tend = 0.0f; // (cut groups: a ray that misses the grid has "left" it)
 		// Phase alignment (as in the beam kernel): w = sx*cx + sy*cy + sz*cz grows by one per step, rays of one octant
 		// can only meet in a cell at equal w, so rays up to WK_MAXLAG steps ahead of the rearmost ray of their
 		// cluster wait that many steps.  (Waiting changes no result.)
@@ -232,11 +267,27 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 				}
 			}
 		}
+		// a later segment of a cut group is given the rays that walked as far as its first window in the launch before
+		// (after the alignment, which has to be the one of the whole group: a ray is in the same cells in window w in
+		// every segment)
+		u32 wprev = 0xFFFFFFFFu; // windows the ray walked in the launch before: a cut group looks at no cell of the ray beyond them
+		if (nseg > 1u) {
+			wprev = inb ? sp.walked_prev[pb] : 0u;
+			if (seg != 0u)
+				walking = walking && wprev > wbeg;
+		}
 		// (The specification also bounds the walk by dims[0]+dims[1]+dims[2]+3 steps.  Every step that stays inside
 		// uses up one of the sum(dims) - 3 steps the three axes have left, so that bound is never reached and is not
 		// carried along here.)
 		__syncthreads();
 		while (__ballot(walking) != 0ull) {
+			if (widx == wend)
+				break; // the segment ends here; its rays that still walk are another segment's from this window on
+			const bool ff = widx < wbeg; // windows before the segment: the walk alone, no cell is looked at
+			u32 wjobs = 0u;
+			if (widx >= wprev)
+				walking = false; // (as far as the ray went the last time: whether that was far enough is settled with the merge)
+			nwin += walking ? 1u : 0u;
 			if (COUNT)
 				st_win++;
 			WK_STAMP(7);
@@ -285,13 +336,15 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 				}
 				ended = (E >> lane) & 1ull;
 				vmask = ((1u << vcount) - 1u) << vfirst; // the steps this ray took: a run of `vcount` from `vfirst`
-				u32 bw[WK_AHEAD];
+				if (!ff) {
+					u32 bw[WK_AHEAD];
 #pragma unroll
-				for (int q = 0; q < WK_AHEAD; q++)
-					bw[q] = bitmap[pcell[q] >> 5];
+					for (int q = 0; q < WK_AHEAD; q++)
+						bw[q] = bitmap[pcell[q] >> 5];
 #pragma unroll
-				for (int q = 0; q < WK_AHEAD; q++)
-					nem |= (((vmask >> q) & (bw[q] >> (pcell[q] & 31u))) & 1u) << q;
+					for (int q = 0; q < WK_AHEAD; q++)
+						nem |= (((vmask >> q) & (bw[q] >> (pcell[q] & 31u))) & 1u) << q;
+				}
 			}
 			if (COUNT) {
 				// (every slot's exit is needed to find the step a ray stopped in)
@@ -319,37 +372,39 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 				//    in step order, at most WK_JOBCAP per pass
 				u32 qnext = 0u;
 				while (qnext < (u32)WK_AHEAD) {
-					u32 njobs = 0u;
-					for (; qnext < (u32)WK_AHEAD && njobs <= (u32)(WK_JOBCAP - 64); qnext++) {
+					// job j of the pass is held by lane j: its cell, its step, and (below) its list; the job loop reads them
+					// with v_readlane into scalar registers (as LDS arrays every job began with four dependent LDS round trips)
+					u32 njobs = 0u, jc = 0u, jq = 0u;
+					for (; qnext < (u32)WK_AHEAD; qnext++) {
 						if (!((qmask >> qnext) & 1u))
 							continue;
 						const bool part = walking && ((nem >> qnext) & 1u);
-						const u32 cell = part ? s_cell[qnext][lane] : 0u;
 						unsigned long long todo = __ballot(part);
+						if (njobs != 0u && njobs + (u32)__popcll(todo) > (u32)WK_JOBCAP)
+							break; // (the step's distinct cells are at most its rays: it goes to the next pass whole)
+						const u32 cell = part ? s_cell[qnext][lane] : 0u;
 						while (todo != 0ull) {
 							const int l = (int)__builtin_ctzll(todo);
 							const u32 X = (u32)__builtin_amdgcn_readlane((int)cell, l);
 							todo &= ~__ballot(part && cell == X);
-							if (lane == 0) {
-								s_jcell[njobs] = X;
-								s_jq[njobs] = (unsigned char)qnext;
-							}
+							jc = d_writelane(jc, X, njobs);
+							jq = d_writelane(jq, qnext, njobs);
 							njobs++;
 						}
 					}
-					__syncthreads();
 					// the headers of the jobs' cells: one lane per job
-					for (u32 j = (u32)lane; j < njobs; j += 64u) {
-						const u32 X = s_jcell[j];
-						s_jbase[j] = offset[X];
-						s_jlen[j] = span[X];
+					u32 jb = 0u, jl = 1u;
+					if ((u32)lane < njobs) {
+						jb = offset[jc];
+						jl = span[jc];
 					}
-					__syncthreads();
 					WK_STAMP(1);
 					// 3. the jobs in step order; the triangle ids of job j+2 and the records of job j+1 are in flight while
 					//    job j is tested (every lane loads, beyond the end of a list the last triangle again, and past the
 					//    last job the last job again: the number of loads in flight does not depend on the data)
-#define WK_JOB_ID(J) value_list[s_jbase[J] + min((u32)lane, s_jlen[J] - 1u)]
+#define WK_JOB_ID(J)                                                               \
+	value_list[(u32)__builtin_amdgcn_readlane((int)jb, (int)(J)) +                 \
+		   min((u32)lane, (u32)__builtin_amdgcn_readlane((int)jl, (int)(J)) - 1u)]
 					u32 idA = 0u, fN = 0u;
 					float rN[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 					if (njobs > 0u) {
@@ -371,7 +426,8 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 						fN = idA;
 						d_load_record<REC>(rec, verts, tris, fN, rN);
 						idA = WK_JOB_ID(min(j + 2u, njobs - 1u));
-						const u32 X = s_jcell[j], q = s_jq[j], base = s_jbase[j], S = s_jlen[j];
+						const u32 X = (u32)__builtin_amdgcn_readlane((int)jc, (int)j), q = (u32)__builtin_amdgcn_readlane((int)jq, (int)j);
+						const u32 base = (u32)__builtin_amdgcn_readlane((int)jb, (int)j), S = (u32)__builtin_amdgcn_readlane((int)jl, (int)j);
 						bool in = walking && ((nem >> q) & 1u) && s_cell[q][lane] == X;
 						float tin = 0.0f;
 						if (in) {
@@ -394,6 +450,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 						if (grpm == 0ull)
 							continue; // every ray of the job ended in an earlier step of this window
 						const u32 n = (u32)__popcll(grpm);
+						wjobs++;
 						if (COUNT) {
 							st_jobs++;
 							st_jrays += n;
@@ -486,6 +543,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 								if (jt < best_t) {
 									best_t = jt;
 									best_ref = (u32)k;
+									best_behind = jt < tin;
 								}
 							}
 							if (best_ref != WK_NONE && best_t <= s_tnext[q][lane]) {
@@ -517,16 +575,81 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 				} else {
 					if (COUNT)
 						n_cells += (u32)__popc(vmask);
-					if (ended)
+					if (ended) {
 						walking = false;
+						tend = tcur;
+					}
 				}
 			}
+			// what the next launch cuts the long groups by: the jobs of this window
+			if (sp.fb && wjobs != 0u && lane == 0)
+				sp.fb[(size_t)d_group_key(sp.chunk, grp, RPW) * WK_FBW + (widx < (u32)WK_FBW ? widx : (u32)WK_FBW - 1u)] =
+					(unsigned char)(wjobs < 255u ? wjobs : 255u);
+			widx++;
 			if (COUNT)
 				__syncthreads(); // (s_tnext is rewritten by the next window's plan)
 		}
-		if (inb) {
-			hit_t[p] = hitstop ? best_t : -1.0f;
-			hit_id[p] = hitstop ? (int)value_list[best_ref] : -2;
+		if (nseg == 1u) {
+			if (inb) {
+				hit_t[p] = hitstop ? best_t : -1.0f;
+				hit_id[p] = hitstop ? (int)value_list[best_ref] : -2;
+				if (sp.walked) {
+					sp.walked[pb] = nwin;
+					sp.walked_prev[pb] = 0xFFFFFFFFu; // (this array is the next launch's `walked`: its segments take minima)
+				}
+			}
+			redo = 0ull;
+		} else {
+			// Split walks.  A segment walks its rays from the start (windows before its own without looking at a cell) and
+			// tests the cells of its windows as if nothing had been hit before; the segments of a group run on different
+			// waves at the same time, each with the rays that walked as far as its windows in the launch before, and none
+			// looks further than a ray went then.  Per ray the sequential walk's result is the smallest (t, segment,
+			// position) over the segments' closest hits: a hit found further along the walk with a smaller t lies in an
+			// earlier cell, whose list holds its triangle too.  It is valid if its t is not beyond the exit of the last
+			// cell that was looked at (the segments' windows join up) or the ray has left the grid.  Otherwise - the ray
+			// goes further than the last time - and where the argument rests on the lists alone - the winner was found by
+			// a later segment BEHIND the entry of its cell - the ray is walked again in one piece.  The last segment to
+			// finish writes the group's results.
+			if (inb && (nwin != 0u || seg == 0u)) {
+				if (best_ref != WK_NONE)
+					atomicMin(&sp.key[pb], ((unsigned long long)__float_as_uint(best_t) << 32) | ((unsigned long long)seg << 29) |
+								      ((unsigned long long)((best_behind && seg != 0u) ? 1u : 0u) << 28) | (unsigned long long)best_ref);
+				if (tend != __builtin_huge_valf())
+					atomicMin(&sp.tend[pb], __float_as_uint(tend));
+				atomicMax(&sp.texam[pb], hitstop ? 0x7F800000u : __float_as_uint(tcur));
+				if (!walking) // (the first segment the ray ends in; later ones walk past its hit.  A ray that still walks where
+					      // the segment ends goes on in the next one)
+					atomicMin(&sp.walked[pb], nwin);
+			}
+			__threadfence();
+			u32 fin = 0u;
+			if (lane == 0)
+				fin = atomicAdd(&sp.done[grp], 1u);
+			fin = (u32)__builtin_amdgcn_readfirstlane((int)fin);
+			redo = 0ull;
+			if (fin == nseg - 1u) {
+				__threadfence();
+				bool again = false;
+				if (inb) {
+					const unsigned long long k = __hip_atomic_load(&sp.key[pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const u32 teb = __hip_atomic_load(&sp.tend[pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const float tx = __uint_as_float(__hip_atomic_load(&sp.texam[pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+					const float kt = __uint_as_float((u32)(k >> 32));
+					const bool left = teb != 0xFFFFFFFFu;
+					const bool hit = k != ~0ull && kt <= (left ? __uint_as_float(teb) : tx);
+					// (the merge state as the next launch expects to find it)
+					sp.key[pb] = ~0ull;
+					sp.tend[pb] = 0xFFFFFFFFu;
+					sp.texam[pb] = 0u;
+					sp.walked_prev[pb] = 0xFFFFFFFFu;
+					again = (!hit && !left) || (hit && ((k >> 28) & 1ull));
+					hit_t[p] = hit ? kt : -1.0f;
+					hit_id[p] = hit ? (int)value_list[(u32)k & 0x0FFFFFFFu] : -2;
+				}
+				redo = __ballot(again);
+				if (lane == 0)
+					sp.done[grp] = 0u;
+			}
 		}
 		if (COUNT) {
 			if (inb) {
@@ -565,23 +688,189 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			}
 		}
 		__syncthreads(); // the next group's rays overwrite s_ray
+		if (redo != 0ull)
+			continue; // (the same group once more, whole, for the rays of `redo`)
 		if (lane == 0)
-			grp = gridDim.x + atomicAdd(ticket, 1u);
-		grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
-	} // groups
+			it = gridDim.x + atomicAdd(ticket, 1u);
+		it = (u32)__builtin_amdgcn_readfirstlane((int)it);
+	} // work items
+}
+
+// The cut groups of the launch that follows (one thread per group): a group whose jobs in the LAST launch of the same
+// ray list (same number of rays, same rays per wave: the history in sp.fb) came to more than LOAD percent of the average
+// group's is cut into up to WK_MAXSEG segments of windows with about equal jobs.  FORCE >= 2 cuts every group into that
+// many segments of three windows (tests).  Also clears the history for the launch that follows, and sets up the merge
+// state of the cut groups' rays.  hdr_prev / hdr_next: the header words of the launch before / after this one.
+#define SEG_THREADS 256
+__global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restrict__ list, const u32 *__restrict__ count_p, u32 RPW,
+							      WalkSplit sp, uint2 *__restrict__ items, unsigned char *__restrict__ cut,
+							      const u32 *__restrict__ hdr_prev, u32 *__restrict__ hdr_next, u32 LOAD, u32 FORCE,
+							      u32 maxg)
+{
+	__shared__ u32 s_red[SEG_THREADS / 64];
+	const u32 t = threadIdx.x, g = blockIdx.x * SEG_THREADS + t;
+	const u32 count = *count_p;
+	u32 nb = (u32)(((unsigned long long)count + RPW - 1u) / RPW);
+	nb = nb < maxg ? nb : maxg;
+	if (g == 0u) {
+		sp.hdr[0] = count;
+		sp.hdr[1] = RPW;
+		hdr_next[2] = 0u; // (the counters of the launch after this one)
+		hdr_next[3] = 0u;
+	}
+	// the average group's jobs are the launch's before the last (the sum this kernel forms is ready after it); the
+	// history is kept under pixels and spans of pixels, so it serves a list of other rays as far as it goes
+	const bool valid = hdr_prev[1] == RPW && hdr_prev[3] != 0u;
+	const u32 limit = nb ? (u32)(((unsigned long long)hdr_prev[3] * LOAD) / ((unsigned long long)nb * 100ull)) + 1u : 1u;
+	u32 jobs = 0u, m = 0u;
+	u32 fw[WK_FBW];
+	unsigned char *f = nullptr;
+	if (g < nb) {
+		f = sp.fb + (size_t)d_group_key(sp.chunk, g, RPW) * WK_FBW;
+		const uint4 *f4 = reinterpret_cast<const uint4 *>(f);
+#pragma unroll
+		for (int q = 0; q < WK_FBW / 16; q++) {
+			const uint4 x = f4[q];
+			const u32 w[4] = { x.x, x.y, x.z, x.w };
+#pragma unroll
+			for (int k = 0; k < 16; k++)
+				fw[q * 16 + k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+		}
+#pragma unroll
+		for (int w = 0; w < WK_FBW; w++)
+			jobs += fw[w];
+		m = FORCE >= 2u ? FORCE : (valid ? (jobs + limit - 1u) / limit : 1u);
+		m = m < 1u ? 1u : (m > (u32)WK_MAXSEG ? (u32)WK_MAXSEG : m);
+		cut[g] = m > 1u ? 1 : 0;
+	}
+	// places in the list: one atomic per wave (a few hundred groups are cut: one each would be ~6 us on one word)
+	{
+		const u32 mine = m > 1u ? m : 0u;
+		u32 incl = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			const u32 o = (u32)__shfl_up((int)incl, d);
+			if ((t & 63u) >= (u32)d)
+				incl += o;
+		}
+		const u32 wave_total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+		u32 base = 0u;
+		if (wave_total != 0u) {
+			if ((t & 63u) == 0u)
+				base = atomicAdd(&sp.hdr[2], wave_total);
+			base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+		}
+		if (m > 1u) {
+			u32 at = base + incl - mine;
+			// segment s ends before the first window by which (s + 1) / m of the jobs have been seen
+			u32 w = 0u, acc = 0u, first = 0u;
+			for (u32 sgm = 0; sgm < m; sgm++) {
+				u32 end = 0xFFFFu;
+				if (sgm + 1u < m) {
+					if (FORCE >= 2u) {
+						end = 3u * (sgm + 1u);
+					} else {
+						const u32 want = (u32)(((unsigned long long)jobs * (sgm + 1u)) / m);
+						while (w < (u32)WK_FBW - 1u && acc + fw[w] <= want) {
+							acc += fw[w];
+							w++;
+						}
+						end = w > first ? w : first + 1u; // (at least one window)
+						w = end < (u32)WK_FBW - 1u ? end : (u32)WK_FBW - 1u;
+					}
+				}
+				items[at++] = make_uint2(g | (sgm << 24) | (m << 28), first | (end << 16));
+				first = end;
+			}
+		}
+	}
+	if (g < nb) {
+		uint4 *z = reinterpret_cast<uint4 *>(f);
+#pragma unroll
+		for (int q = 0; q < WK_FBW / 16; q++)
+			z[q] = make_uint4(0u, 0u, 0u, 0u);
+	}
+	u32 sum = jobs;
+#pragma unroll
+	for (int m = 32; m >= 1; m >>= 1)
+		sum += (u32)__shfl_xor((int)sum, m);
+	if ((t & 63u) == 0u)
+		s_red[t >> 6] = sum;
+	__syncthreads();
+	if (t == 0u) {
+		u32 all = 0u;
+		for (int w = 0; w < SEG_THREADS / 64; w++)
+			all += s_red[w];
+		if (all)
+			atomicAdd(&sp.hdr[3], all);
+	}
+}
+
+// split walks (option dda_split: 0 off, 1 = by the last launch's job counts, 2..WK_MAXSEG = every group, for tests): the
+// state of this launch; the merge key holds a list position in 28 bits, the history is kept per group of >= 16 rays
+int ugrt_dda_split_state(ugrt_ctx *ctx, u32 RPW, u32 total_refs, WalkSplit *sp, WalkSplitHost *sph)
+{
+	const int mode = ctx->opt[UGRT_OPT_DDA_SPLIT] >= 0 ? ctx->opt[UGRT_OPT_DDA_SPLIT] : 1;
+	if (mode == 0 || RPW < 16u || (64u % RPW) != 0u || total_refs >= (1u << 28))
+		return UGRT_OK;
+	const size_t npix = (size_t)ctx->npix, maxg = (npix + 63) / 64 * (64 / RPW) + 64 / RPW, nchunk = (npix + 63) / 64 + 1;
+	// three header blocks in turn (this launch's, the one before, the one after), two `walked` arrays in turn
+	const size_t o_items = 3 * 64, o_fb = o_items + maxg * WK_MAXSEG * sizeof(uint2), o_done = o_fb + maxg * WK_FBW,
+		     o_cut = o_done + maxg * 4, o_chunk = (o_cut + maxg + 15) / 16 * 16, o_key = (o_chunk + nchunk * 4 + 15) / 16 * 16,
+		     o_tend = o_key + npix * 8, o_texam = o_tend + npix * 4, o_walked = o_texam + npix * 4, bytes = o_walked + 2 * npix * 4;
+	const void *before = ctx->dsplit.p;
+	int rc = ugrt_buf_reserve(ctx, ctx->dsplit, bytes);
+	if (rc)
+		return rc;
+	if (ctx->dsplit.p != before || ctx->dsplit_rpw != RPW) { // no history yet (or one laid out for other groups)
+		UGRT_HIP(hipMemsetAsync(ctx->dsplit.p, 0, ctx->dsplit.cap, ctx->stream));
+		// the merge state of a ray at rest: no hit (all ones), not seen leaving (all ones), nothing looked at (0); no ray
+		// has a history ("walked everywhere")
+		UGRT_HIP(hipMemsetAsync((char *)ctx->dsplit.p + o_key, 0xFF, npix * 12, ctx->stream));
+		UGRT_HIP(hipMemsetAsync((char *)ctx->dsplit.p + o_walked, 0xFF, 2 * npix * 4, ctx->stream));
+		ctx->dsplit_rpw = RPW;
+		ctx->dsplit_turn = 0;
+	}
+	const u32 turn = ctx->dsplit_turn++;
+	char *b = (char *)ctx->dsplit.p;
+	sp->hdr = (u32 *)(b + 64 * (turn % 3u));
+	sp->items = (const uint2 *)(b + o_items);
+	sp->cut = (const unsigned char *)(b + o_cut);
+	sp->fb = (unsigned char *)(b + o_fb);
+	sp->chunk = (const u32 *)(b + o_chunk);
+	sp->done = (u32 *)(b + o_done);
+	sp->key = (unsigned long long *)(b + o_key);
+	sp->p0 = (u32)ctx->p0;
+	sp->tend = (u32 *)(b + o_tend);
+	sp->texam = (u32 *)(b + o_texam);
+	sp->walked = (u32 *)(b + o_walked) + (size_t)(turn & 1u) * npix;
+	sp->walked_prev = (u32 *)(b + o_walked) + (size_t)((turn + 1u) & 1u) * npix;
+	sph->items = (uint2 *)(b + o_items);
+	sph->cut = (unsigned char *)(b + o_cut);
+	sph->hdr_prev = (const u32 *)(b + 64 * ((turn + 2u) % 3u));
+	sph->hdr_next = (u32 *)(b + 64 * ((turn + 1u) % 3u));
+	sph->load = ctx->opt[UGRT_OPT_DDA_SPLIT_LOAD] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_SPLIT_LOAD] : 400u;
+	sph->force = mode >= 2 ? (u32)mode : 0u;
+	sph->maxg = (u32)maxg;
+	return UGRT_OK;
 }
 
 // launched by ugrt_trace_dda (ugrt_dda.hip) behind k_dda_prepare, which also wrote `bitmap` ((ncell + 63) / 64 * 2 words)
 int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
 			 u32 *bitmap, const float *d_vertlist, const int *d_trilist, const float4 *rec, const float *d_rays,
 			 const u32 *list, const u32 *dcount, float *d_hit_t, int *d_hit_id, unsigned long long *counters,
-			 bool counting, u32 RPW, u32 CULL_MIN, u32 CULL_WORK, int blocks)
+			 bool counting, u32 RPW, u32 CULL_MIN, u32 CULL_WORK, int blocks, const WalkSplit &sp, const WalkSplitHost &sph)
 {
 	u32 *ticket = ctx->d_small + UGRT_DSMALL_TICKET;
+	if (sp.items) {
+		hipLaunchKernelGGL(k_dda_segments, dim3((sph.maxg + SEG_THREADS - 1) / SEG_THREADS), dim3(SEG_THREADS), 0, ctx->stream, list,
+				   dcount, RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg);
+		UGRT_HIP(hipGetLastError());
+	}
 #define WK_LAUNCH(CNTV, RECV)                                                                                          \
 	hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
 			   d_offset, (const u32 *)bitmap, d_vertlist, d_trilist, rec, d_rays, list, dcount, d_hit_t, d_hit_id, \
-			   counters, RPW, CULL_MIN, CULL_WORK, ticket)
+			   counters, RPW, CULL_MIN, CULL_WORK, ticket, sp)
 	if (counting) {
 		if (rec)
 			WK_LAUNCH(true, true);

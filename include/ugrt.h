@@ -330,6 +330,10 @@ int ugrt_stats_get(ugrt_ctx *ctx, unsigned long long stats[8]);
  * those rounds, [7] exact tests of lone rays, [8..23] waves by log2(shader cycles / 4096), [24] sum and
  * [25] maximum of the waves' cycles; entries past n are not written, entries past 25 are 0 */
 int ugrt_stats_dda(ugrt_ctx *ctx, unsigned long long *stats, int n);
+/* split walks of the context's last ugrt_trace_dda (option "dda_split"; synchronises the stream): [0] segments the
+ * cut ray groups were listed as, [1] jobs of the launch before, [2] cut groups some of whose rays had to be walked
+ * again in one piece, [3] those rays */
+int ugrt_stats_dda_split(ugrt_ctx *ctx, unsigned out[4]);
 /* The same for the primary tracer: [0] work items (tile x list segment), [1] batches of 64 references culled,
  * [2] batches with a survivor of the tile's box, [3] references, [4] survivors of the tile's box, [5] survivors of a
  * quadrant's box (staged in LDS), [6] jobs (survivor x quadrant), [7] flushes, [8] exact rounds (4 jobs x 16 rays),

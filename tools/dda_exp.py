@@ -57,7 +57,7 @@ for rep in range(3):
                     r.hit_id.fill_(7)
                     ms = run(ctx, r)
                     same = bool((r.hit_id == ref_id).all()) and bool((r.hit_t.view(torch.int32) == ref_t.view(torch.int32)).all())
-                    print("rpw %2d waves %4d split %d load %4d: %.4f ms identical=%s" % (rpw, blk, split, load, ms, same), flush=True)
+                    print("rpw %2d waves %4d split %d load %4d: %.4f ms identical=%s %s" % (rpw, blk, split, load, ms, same, ctx.stats_dda_split() if split else ""), flush=True)
                     res["rows"].append({"rpw": rpw, "waves": blk, "split": split, "load": load, "ms": ms, "identical": same})
 cctx, cr = make(ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_COUNT_WORK)
 cctx.set_option("dda_kernel", 0)

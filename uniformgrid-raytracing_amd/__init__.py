@@ -151,6 +151,7 @@ PROTOTYPES = {
     "ugrt_prof_get": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ugrt_stats_get": (C.c_int, [_P, C.POINTER(C.c_ulonglong)]),
     "ugrt_stats_dda": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.c_int]),
+    "ugrt_stats_dda_split": (C.c_int, [_P, C.POINTER(C.c_uint)]),
     "ugrt_stats_primary": (C.c_int, [_P, C.POINTER(C.c_ulonglong), C.c_int]),
 }
 

@@ -647,8 +647,13 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 					hit_id[p] = hit ? (int)value_list[(u32)k & 0x0FFFFFFFu] : -2;
 				}
 				redo = __ballot(again);
-				if (lane == 0)
+				if (lane == 0) {
 					sp.done[grp] = 0u;
+					if (redo != 0ull) { // (ugrt_stats_dda_split)
+						atomicAdd(&sp.hdr[4], 1u);
+						atomicAdd(&sp.hdr[5], (u32)__popcll(redo));
+					}
+				}
 			}
 		}
 		if (COUNT) {
@@ -717,6 +722,8 @@ __global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restr
 		sp.hdr[1] = RPW;
 		hdr_next[2] = 0u; // (the counters of the launch after this one)
 		hdr_next[3] = 0u;
+		hdr_next[4] = 0u;
+		hdr_next[5] = 0u;
 	}
 	// the average group's jobs are the launch's before the last (the sum this kernel forms is ready after it); the
 	// history is kept under pixels and spans of pixels, so it serves a list of other rays as far as it goes
@@ -893,5 +900,23 @@ int ugrt_dda_sort_keys_launch(ugrt_ctx *ctx, const DGrid &g, const float *d_rays
 {
 	hipLaunchKernelGGL(k_dda_sort_keys, dim3((cap + 255u) / 256u), dim3(256), 0, ctx->stream, g, d_rays, list, dcount, cap, keys);
 	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}
+
+// what the split walks of the context's last bounce did (synchronises the stream): [0] segments the cut groups were
+// listed as, [1] jobs of the launch before (what the groups were measured against), [2] cut groups that had rays
+// walked again in one piece, [3] those rays
+extern "C" int ugrt_stats_dda_split(ugrt_ctx *ctx, unsigned out[4])
+{
+	if (!ctx || !out)
+		return ugrt_fail(UGRT_EINVAL, "stats_dda_split: null argument");
+	UGRT_HIP(hipSetDevice(ctx->device));
+	out[0] = out[1] = out[2] = out[3] = 0u;
+	if (!ctx->dsplit.p || ctx->dsplit_turn == 0u)
+		return UGRT_OK;
+	u32 h[8];
+	UGRT_HIP(hipMemcpyAsync(h, (const char *)ctx->dsplit.p + 64 * ((ctx->dsplit_turn - 1u) % 3u), sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+	UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	out[0] = h[2], out[1] = h[3], out[2] = h[4], out[3] = h[5];
 	return UGRT_OK;
 }

@@ -260,6 +260,13 @@ class Context:
 
     WALK_STATS = ("windows", "jobs", "job_rays", "cull_batches", "cull_tests", "rounds", "round_pairs", "empty_windows")
 
+    def stats_dda_split(self):
+        """Split walks of the last trace_dda (option dda_split): segments the cut groups were listed as, jobs of the launch
+        before, cut groups with rays that were walked again in one piece, those rays."""
+        a = (C.c_uint * 4)()
+        check(lib.ugrt_stats_dda_split(self._h, a))
+        return dict(zip(("segments", "jobs_of_the_launch_before", "groups_walked_again", "rays_walked_again"), list(a)))
+
     def stats_dda(self, kernel=0):
         """Work sharing of the bounce kernel's last counting launch (a FLAG_COUNT_WORK context); `kernel` = the
         "dda_kernel" option it ran with (0 window kernel, 2 beam kernel of round 2: the counters' meanings differ)."""

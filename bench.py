@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 DDA_WAVES_THROUGHPUT, DDA_WAVES_ONE_FRAME = 3072, 1024
 DDA_RPW_THROUGHPUT = 64
+DDA_SPLIT_THROUGHPUT = 0  # split walks of the bounce (ugrt.h "dda_split"): off beside other frames, on (the default) alone
 SHADOW_WAVES_THROUGHPUT = 4096
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -350,6 +351,10 @@ def main():
                 # one-frame figure below is measured with), but it issues fewer instructions in all, and beside three
                 # other frames that is what counts (1.214 -> 1.195 ms per frame)
                 rr.aux.set_option("dda_rays_per_wave", DDA_RPW_THROUGHPUT)
+                # split walks (the long ray groups of the last bounce cut into segments on different waves) shorten the
+                # bounce by 5-15 % and one frame in flight by 2-3 %, but add a launch and the segments' extra windows: beside
+                # three other frames the chip has no idle waves to give them (4 runs: 1.198 against 1.183 ms per frame)
+                rr.aux.set_option("dda_split", DDA_SPLIT_THROUGHPUT)
             for kv in opts:
                 k, v = kv.split("=")
                 for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
@@ -515,13 +520,15 @@ def main():
             rr.synchronize()
         torch.cuda.synchronize()
         repeats.append((time.perf_counter() - r0) / args.steps * 1e3)
+    split_stats = None
     # latency: the same K steps with ONE frame in flight (every frame is finished before the next one is started)
     latency_ms = None
     if len(renderers) > 1:
-        user_waves = [kv for kv in opts if kv.startswith(("dda_blocks=", "shadow_waves=", "dda_rays_per_wave="))]
+        user_waves = [kv for kv in opts if kv.startswith(("dda_blocks=", "shadow_waves=", "dda_rays_per_wave=", "dda_split="))]
         if renderers[0].aux is not None and not user_waves:
             renderers[0].aux.set_option("dda_blocks", DDA_WAVES_ONE_FRAME)
             renderers[0].aux.set_option("dda_rays_per_wave", -1)
+            renderers[0].aux.set_option("dda_split", -1)
             renderers[0].ctx.set_option("shadow_waves", -1)  # the default
         torch.cuda.synchronize()
         r0 = time.perf_counter()
@@ -532,9 +539,14 @@ def main():
         renderers[0].synchronize()
         torch.cuda.synchronize()
         latency_ms = (time.perf_counter() - r0) / args.steps * 1e3
+        # what the bounce's split walks did in the last of those frames
+        if reflect:
+            c0 = renderers[0].aux if renderers[0].aux is not None else renderers[0].ctx
+            split_stats = c0.stats_dda_split()
         if renderers[0].aux is not None and not user_waves:
             renderers[0].aux.set_option("dda_blocks", DDA_WAVES_THROUGHPUT)
             renderers[0].aux.set_option("dda_rays_per_wave", DDA_RPW_THROUGHPUT)
+            renderers[0].aux.set_option("dda_split", DDA_SPLIT_THROUGHPUT)
             renderers[0].ctx.set_option("shadow_waves", SHADOW_WAVES_THROUGHPUT)
     # untimed pass: the full stage table (with two streams the stages overlap: their sum exceeds the frame)
     for c in profiled:
@@ -729,6 +741,8 @@ def main():
                                      "one_frame_in_flight": 32},
             "shadow_waves": {"frames_in_flight": SHADOW_WAVES_THROUGHPUT if len(renderers) > 1 else 8192,
                              "one_frame_in_flight": 8192},
+            "bounce_split_walks": {"frames_in_flight": bool(DDA_SPLIT_THROUGHPUT) if len(renderers) > 1 else True,
+                                   "one_frame_in_flight": True, "last_one_frame_in_flight": split_stats},
             "host_waits_inside_a_frame": bool(args.waiting_builds),
             "static_geometry": not args.no_static_geometry,  # UGRT_FLAG_STATIC_GEOMETRY: triangle records kept between builds
             "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,

@@ -373,6 +373,45 @@ def test_animation(ugrt, O, torch):
     np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"])
 
 
+@pytest.mark.parametrize("rpw", [32, 64])
+def test_bounce_split_walks_on_a_moving_scene(ugrt, torch, rpw):
+    """Split walks with a history that does NOT hold: the animated part of the scene turns every frame, rays end
+    elsewhere than the frame before, and the rays a cut group's segments could not vouch for go on from where the
+    segments stopped looking.  A context with split walks (cutting every group above half the average) against one
+    without, frame by frame: the bounce's results and the image bit for bit; and the cut groups did have rays that
+    went on (the path is exercised), in both tile-row bands of a two-band split too."""
+    s = scene(ugrt, "crash")
+    W, H, lg = 512, 288, (64, 64)
+    setup = setup_for(ugrt, s, "ref")
+    for rows in (None, (H // 8 // 2, H // 8)):
+        pair = []
+        for split in (0, 1):
+            ctx, r = make(ugrt, s, W, H, lg, rows=rows, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS)
+            r.init_orig_list(s["animated_size"], s["animated_offset"])
+            ctx.set_option("dda_split", split)
+            ctx.set_option("dda_split_load", 50)
+            ctx.set_option("dda_rays_per_wave", rpw)
+            pair.append((ctx, r))
+        went_on = cut_frames = 0
+        for frame in range(8):
+            rot = 1.81 + 0.05 * frame
+            for ctx, r in pair:
+                r.rotate_bunny(rot)
+                r.display(setup, shadows=False, reflect=True)
+                ctx.synchronize()
+            (c0, r0), (c1, r1) = pair
+            what = "frame %d, rows %r" % (frame, rows)
+            lo, hi = (0, W * H) if rows is None else (rows[0] * 8 * W, rows[1] * 8 * W)  # (a band context writes its band)
+            np.testing.assert_array_equal(r1.hit_id.cpu().numpy()[lo:hi], r0.hit_id.cpu().numpy()[lo:hi], err_msg=what)
+            assert_bits_equal(r1.hit_t.cpu().numpy()[lo:hi], r0.hit_t.cpu().numpy()[lo:hi], "bounce t, " + what)
+            np.testing.assert_array_equal(r1.image.cpu().numpy()[3 * lo:3 * hi], r0.image.cpu().numpy()[3 * lo:3 * hi], err_msg=what)
+            st = c1.stats_dda_split()
+            went_on += st["rays_walked_again"]
+            cut_frames += 1 if st["segments"] else 0
+        # (after a launch most of whose cut groups had such rays the context cuts nothing for 1, 2, 4 ... launches)
+        assert went_on > 0 and 2 <= cut_frames < 6, (went_on, cut_frames)
+
+
 def test_band_split_equals_full_frame(ugrt, O, torch):
     """Image-tile sharding (multi-GPU path): two contexts with complementary tile-row bands
     produce exactly the full frame's primary outputs and the oracle's band results."""

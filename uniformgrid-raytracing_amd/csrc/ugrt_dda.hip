@@ -764,7 +764,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	// split walks of the window kernel (ugrt_dda_walk.hip): list positions go into 28 bits of their merge key, and the
 	// context's own grid tells how many there are
 	WalkSplit sp = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr };
-	WalkSplitHost sph = { nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+	WalkSplitHost sph = {};
 	if (kernel == 0 && !counting && ctx->opt[UGRT_OPT_DDA_SORT] != 1 &&
 	    (rc = ugrt_dda_split_state(ctx, DDA_RPW, d_span == (const unsigned *)G.span.p && d_offset == (const unsigned *)G.offset.p ? G.R : 0xFFFFFFFFu,
 				       &sp, &sph)))

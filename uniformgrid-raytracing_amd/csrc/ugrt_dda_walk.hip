@@ -159,8 +159,14 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 		if (it < ncut) {
 			const uint2 d = sp.items[it];
 			grp = d.x & 0xFFFFFFu;
-			if (redo == 0ull)
+			if (redo == 0ull) {
 				seg = (d.x >> 24) & 15u, nseg = d.x >> 28, wbeg = d.y & 0xFFFFu, wend = d.y >> 16;
+			} else if (lane == 0) {
+				// (ugrt_stats_dda_split, and what the next launch judges the history by.  Counted here, where the ray goes on:
+				// next to the merge the same two lines cost 150 bytes of spilled registers per lane)
+				atomicAdd(&sp.hdr[4], 1u);
+				atomicAdd(&sp.hdr[5], (u32)__popcll(redo));
+			}
 		} else if (sp.cut && sp.cut[grp]) { // (a cut group's turn as a whole group: nothing to do)
 			if (lane == 0)
 				it = gridDim.x + atomicAdd(ticket, 1u);
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			continue;
 		}
 		const u32 slot = grp * RPW + (u32)lane;
-		bool inb = (u32)lane < RPW && slot < count && (redo == 0ull || ((redo >> lane) & 1ull));
+		bool inb = (u32)lane < RPW && slot < count;
 		const int p = inb ? (int)list[slot] : 0;
 		inb = inb && p != -1; // (the list is padded to whole chunks of 64 entries per span of pixels: k_dda_prepare)
 		const u32 pb = (u32)p - sp.p0; // the ray's index in the split walks' per-pixel arrays
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 		u32 best_ref = WK_NONE; // list position of the closest hit so far (value_list[best_ref] is its triangle)
 		bool walking = false, hitstop = false;
 		bool best_behind = false;               // (cut groups) the closest hit lies before the entry of the cell it was found in
-		float tend = __builtin_huge_valf();     // (cut groups) exit parameter of the last cell, once the ray has left the grid
+		bool left = false;                      // (cut groups) the ray has left the grid (tcur is then the exit of its last cell) or misses it
 		u32 widx = 0u;                          // window number
 		u32 nwin = 0u;                          // windows this ray has walked
 		// set-up: exactly the arithmetic of the per-ray kernel and of the specification
@@ -251,8 +257,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			*reinterpret_cast<float2 *>(&s_ray[lane * 8 + 4]) = make_float2(d[1], d[2]);
 			s_best[lane] = ~0ull;
 		}
-		if (inb && !walking)
-			tend = 0.0f; // (cut groups: a ray that misses the grid has "left" it)
+		left = inb && !walking; // (cut groups: a ray that misses the grid has "left" it)
 		// Phase alignment (as in the beam kernel): w = sx*cx + sy*cy + sz*cz grows by one per step, rays of one octant
 		// can only meet in a cell at equal w, so rays up to WK_MAXLAG steps ahead of the rearmost ray of their
 		// cluster wait that many steps.  (Waiting changes no result.)
@@ -275,6 +280,23 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			wprev = inb ? sp.walked_prev[pb] : 0u;
 			if (seg != 0u)
 				walking = walking && wprev > wbeg;
+		} else if (redo != 0ull) {
+			// (only now: the alignment above has to be the whole group's, or the windows would not be the segments' windows)
+			inb = inb && ((redo >> lane) & 1ull);
+			walking = walking && inb;
+		}
+		if (nseg == 1u && redo != 0ull && inb) {
+			// a ray of a cut group whose merged result could not be vouched for goes on from where the segments stopped
+			// looking: it carries their closest hit along and looks at no cell of the windows they covered (wprev of
+			// them) -- or starts afresh, when that hit was one found behind its cell by a later segment
+			const unsigned long long k = sp.key[pb];
+			sp.key[pb] = ~0ull;
+			const bool afresh = k != ~0ull && ((k >> 28) & 1ull);
+			if (k != ~0ull && !afresh) {
+				best_t = __uint_as_float((u32)(k >> 32));
+				best_ref = (u32)k & 0x0FFFFFFFu;
+			}
+			wprev = afresh ? 0u : sp.walked[pb];
 		}
 		// (The specification also bounds the walk by dims[0]+dims[1]+dims[2]+3 steps.  Every step that stays inside
 		// uses up one of the sum(dims) - 3 steps the three axes have left, so that bound is never reached and is not
@@ -283,9 +305,11 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 		while (__ballot(walking) != 0ull) {
 			if (widx == wend)
 				break; // the segment ends here; its rays that still walk are another segment's from this window on
-			const bool ff = widx < wbeg; // windows before the segment: the walk alone, no cell is looked at
+			// windows before the segment, and windows the segments have covered for every ray of a group that is gone over
+			// again: the walk alone, no cell is looked at
+			const bool ff = widx < wbeg || (redo != 0ull && __ballot(walking && widx >= wprev) == 0ull);
 			u32 wjobs = 0u;
-			if (widx >= wprev)
+			if (nseg > 1u && widx >= wprev)
 				walking = false; // (as far as the ray went the last time: whether that was far enough is settled with the merge)
 			nwin += walking ? 1u : 0u;
 			if (COUNT)
@@ -344,6 +368,8 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 #pragma unroll
 					for (int q = 0; q < WK_AHEAD; q++)
 						nem |= (((vmask >> q) & (bw[q] >> (pcell[q] & 31u))) & 1u) << q;
+					if (redo != 0ull && widx < wprev)
+						nem = 0u; // (this ray's cells of the window have been looked at by a segment)
 				}
 			}
 			if (COUNT) {
@@ -577,7 +603,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 						n_cells += (u32)__popc(vmask);
 					if (ended) {
 						walking = false;
-						tend = tcur;
+						left = true;
 					}
 				}
 			}
@@ -610,12 +636,16 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			// goes further than the last time - and where the argument rests on the lists alone - the winner was found by
 			// a later segment BEHIND the entry of its cell - the ray is walked again in one piece.  The last segment to
 			// finish writes the group's results.
+			// (a ray that still walks where the segment ends, and went no further the last time, ends here: no later
+			// segment has it)
+			if (walking && widx >= wprev)
+				walking = false;
 			if (inb && (nwin != 0u || seg == 0u)) {
 				if (best_ref != WK_NONE)
 					atomicMin(&sp.key[pb], ((unsigned long long)__float_as_uint(best_t) << 32) | ((unsigned long long)seg << 29) |
 								      ((unsigned long long)((best_behind && seg != 0u) ? 1u : 0u) << 28) | (unsigned long long)best_ref);
-				if (tend != __builtin_huge_valf())
-					atomicMin(&sp.tend[pb], __float_as_uint(tend));
+				if (left)
+					atomicMin(&sp.tend[pb], __float_as_uint(tcur));
 				atomicMax(&sp.texam[pb], hitstop ? 0x7F800000u : __float_as_uint(tcur));
 				if (!walking) // (the first segment the ray ends in; later ones walk past its hit.  A ray that still walks where
 					      // the segment ends goes on in the next one)
@@ -638,22 +668,19 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 					const bool left = teb != 0xFFFFFFFFu;
 					const bool hit = k != ~0ull && kt <= (left ? __uint_as_float(teb) : tx);
 					// (the merge state as the next launch expects to find it)
-					sp.key[pb] = ~0ull;
+					again = (!hit && !left) || (hit && ((k >> 28) & 1ull));
+					// (the merge state as the next launch expects to find it; a ray that is gone over again picks its key up first)
+					if (!again)
+						sp.key[pb] = ~0ull;
 					sp.tend[pb] = 0xFFFFFFFFu;
 					sp.texam[pb] = 0u;
 					sp.walked_prev[pb] = 0xFFFFFFFFu;
-					again = (!hit && !left) || (hit && ((k >> 28) & 1ull));
 					hit_t[p] = hit ? kt : -1.0f;
 					hit_id[p] = hit ? (int)value_list[(u32)k & 0x0FFFFFFFu] : -2;
 				}
 				redo = __ballot(again);
-				if (lane == 0) {
+				if (lane == 0)
 					sp.done[grp] = 0u;
-					if (redo != 0ull) { // (ugrt_stats_dda_split)
-						atomicAdd(&sp.hdr[4], 1u);
-						atomicAdd(&sp.hdr[5], (u32)__popcll(redo));
-					}
-				}
 			}
 		}
 		if (COUNT) {
@@ -703,101 +730,132 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 
 // The cut groups of the launch that follows (one thread per group): a group whose jobs in the LAST launch of the same
 // ray list (same number of rays, same rays per wave: the history in sp.fb) came to more than LOAD percent of the average
-// group's is cut into up to WK_MAXSEG segments of windows with about equal jobs.  FORCE >= 2 cuts every group into that
+// group's, and to more than one of the launch's WAVES' share of all jobs, is cut into up to WK_MAXSEG segments of windows
+// with about equal jobs.  FORCE >= 2 cuts every group into that
 // many segments of three windows (tests).  Also clears the history for the launch that follows, and sets up the merge
 // state of the cut groups' rays.  hdr_prev / hdr_next: the header words of the launch before / after this one.
 #define SEG_THREADS 256
 __global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restrict__ list, const u32 *__restrict__ count_p, u32 RPW,
 							      WalkSplit sp, uint2 *__restrict__ items, unsigned char *__restrict__ cut,
 							      const u32 *__restrict__ hdr_prev, u32 *__restrict__ hdr_next, u32 LOAD, u32 FORCE,
-							      u32 maxg)
+							      u32 maxg, u32 WAVES)
 {
 	__shared__ u32 s_red[SEG_THREADS / 64];
-	const u32 t = threadIdx.x, g = blockIdx.x * SEG_THREADS + t;
+	const u32 t = threadIdx.x;
 	const u32 count = *count_p;
 	u32 nb = (u32)(((unsigned long long)count + RPW - 1u) / RPW);
 	nb = nb < maxg ? nb : maxg;
-	if (g == 0u) {
+	if (blockIdx.x == 0u && t == 0u) {
 		sp.hdr[0] = count;
 		sp.hdr[1] = RPW;
-		hdr_next[2] = 0u; // (the counters of the launch after this one)
-		hdr_next[3] = 0u;
-		hdr_next[4] = 0u;
-		hdr_next[5] = 0u;
+		for (int i = 2; i <= 6; i++)
+			hdr_next[i] = 0u; // (the counters of the launch after this one)
+	}
+	// Is the history worth cutting by?  When more than half of the groups the launch before cut had rays that went further
+	// than the segments looked (a scene that moves fast), nothing is cut for a while: 1, 2, 4 ... 16 launches.
+	// [7] launches still to sit out, [8] the length of the current pause
+	bool pause = hdr_prev[7] != 0u;
+	{
+		u32 left = pause ? hdr_prev[7] - 1u : 0u, len = hdr_prev[8];
+		if (!pause) {
+			if (hdr_prev[6] != 0u && hdr_prev[4] * 2u > hdr_prev[6]) {
+				len = len ? (2u * len < 16u ? 2u * len : 16u) : 1u;
+				left = len - 1u;
+				pause = true;
+			} else if (hdr_prev[6] != 0u) {
+				len = 0u; // (a launch that cut, and well)
+			}
+		}
+		if (blockIdx.x == 0u && t == 0u) {
+			sp.hdr[7] = left;
+			sp.hdr[8] = len;
+		}
 	}
 	// the average group's jobs are the launch's before the last (the sum this kernel forms is ready after it); the
 	// history is kept under pixels and spans of pixels, so it serves a list of other rays as far as it goes
-	const bool valid = hdr_prev[1] == RPW && hdr_prev[3] != 0u;
-	const u32 limit = nb ? (u32)(((unsigned long long)hdr_prev[3] * LOAD) / ((unsigned long long)nb * 100ull)) + 1u : 1u;
-	u32 jobs = 0u, m = 0u;
-	u32 fw[WK_FBW];
-	unsigned char *f = nullptr;
-	if (g < nb) {
-		f = sp.fb + (size_t)d_group_key(sp.chunk, g, RPW) * WK_FBW;
-		const uint4 *f4 = reinterpret_cast<const uint4 *>(f);
+	const bool valid = hdr_prev[1] == RPW && hdr_prev[3] != 0u && !pause;
+	// ... and more than a wave's share of all jobs: a launch of many more groups than waves has no tail to cut, only
+	// the segments' extra windows to pay
+	u32 limit = nb ? (u32)(((unsigned long long)hdr_prev[3] * LOAD) / ((unsigned long long)nb * 100ull)) + 1u : 1u;
+	const u32 share = hdr_prev[3] / (WAVES ? WAVES : 1u);
+	limit = limit > share ? limit : share;
+	u32 jobs_all = 0u;
+	// (whole waves take part in every turn: the places in the list are dealt per wave)
+	for (u32 g0 = blockIdx.x * SEG_THREADS; g0 < nb; g0 += gridDim.x * SEG_THREADS) {
+		const u32 g = g0 + t;
+		u32 jobs = 0u, m = 0u;
+		u32 fw[WK_FBW];
+		unsigned char *f = nullptr;
+		if (g < nb) {
+			f = sp.fb + (size_t)d_group_key(sp.chunk, g, RPW) * WK_FBW;
+			const uint4 *f4 = reinterpret_cast<const uint4 *>(f);
 #pragma unroll
-		for (int q = 0; q < WK_FBW / 16; q++) {
-			const uint4 x = f4[q];
-			const u32 w[4] = { x.x, x.y, x.z, x.w };
+			for (int q = 0; q < WK_FBW / 16; q++) {
+				const uint4 x = f4[q];
+				const u32 w[4] = { x.x, x.y, x.z, x.w };
 #pragma unroll
-			for (int k = 0; k < 16; k++)
-				fw[q * 16 + k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+				for (int k = 0; k < 16; k++)
+					fw[q * 16 + k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+			}
+#pragma unroll
+			for (int w = 0; w < WK_FBW; w++)
+				jobs += fw[w];
+			m = FORCE >= 2u ? FORCE : (valid ? (jobs + limit - 1u) / limit : 1u);
+			m = m < 1u ? 1u : (m > (u32)WK_MAXSEG ? (u32)WK_MAXSEG : m);
+			cut[g] = m > 1u ? 1 : 0;
 		}
+		// places in the list: one atomic per wave (a few hundred groups are cut: one each would be ~6 us on one word)
+		{
+			const u32 mine = m > 1u ? m : 0u;
+			u32 incl = mine;
 #pragma unroll
-		for (int w = 0; w < WK_FBW; w++)
-			jobs += fw[w];
-		m = FORCE >= 2u ? FORCE : (valid ? (jobs + limit - 1u) / limit : 1u);
-		m = m < 1u ? 1u : (m > (u32)WK_MAXSEG ? (u32)WK_MAXSEG : m);
-		cut[g] = m > 1u ? 1 : 0;
-	}
-	// places in the list: one atomic per wave (a few hundred groups are cut: one each would be ~6 us on one word)
-	{
-		const u32 mine = m > 1u ? m : 0u;
-		u32 incl = mine;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			const u32 o = (u32)__shfl_up((int)incl, d);
-			if ((t & 63u) >= (u32)d)
-				incl += o;
-		}
-		const u32 wave_total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-		u32 base = 0u;
-		if (wave_total != 0u) {
-			if ((t & 63u) == 0u)
-				base = atomicAdd(&sp.hdr[2], wave_total);
-			base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-		}
-		if (m > 1u) {
-			u32 at = base + incl - mine;
-			// segment s ends before the first window by which (s + 1) / m of the jobs have been seen
-			u32 w = 0u, acc = 0u, first = 0u;
-			for (u32 sgm = 0; sgm < m; sgm++) {
-				u32 end = 0xFFFFu;
-				if (sgm + 1u < m) {
-					if (FORCE >= 2u) {
-						end = 3u * (sgm + 1u);
-					} else {
-						const u32 want = (u32)(((unsigned long long)jobs * (sgm + 1u)) / m);
-						while (w < (u32)WK_FBW - 1u && acc + fw[w] <= want) {
-							acc += fw[w];
-							w++;
-						}
-						end = w > first ? w : first + 1u; // (at least one window)
-						w = end < (u32)WK_FBW - 1u ? end : (u32)WK_FBW - 1u;
-					}
+			for (int d = 1; d < 64; d <<= 1) {
+				const u32 o = (u32)__shfl_up((int)incl, d);
+				if ((t & 63u) >= (u32)d)
+					incl += o;
+			}
+			const u32 wave_total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+			u32 base = 0u;
+			if (wave_total != 0u) {
+				if ((t & 63u) == 0u) {
+					base = atomicAdd(&sp.hdr[2], wave_total);
+					atomicAdd(&sp.hdr[6], (u32)__popcll(__ballot(mine != 0u))); // (groups cut)
 				}
-				items[at++] = make_uint2(g | (sgm << 24) | (m << 28), first | (end << 16));
-				first = end;
+				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+			}
+			if (m > 1u) {
+				u32 at = base + incl - mine;
+				// segment s ends before the first window by which (s + 1) / m of the jobs have been seen
+				u32 w = 0u, acc = 0u, first = 0u;
+				for (u32 sgm = 0; sgm < m; sgm++) {
+					u32 end = 0xFFFFu;
+					if (sgm + 1u < m) {
+						if (FORCE >= 2u) {
+							end = 3u * (sgm + 1u);
+						} else {
+							const u32 want = (u32)(((unsigned long long)jobs * (sgm + 1u)) / m);
+							while (w < (u32)WK_FBW - 1u && acc + fw[w] <= want) {
+								acc += fw[w];
+								w++;
+							}
+							end = w > first ? w : first + 1u; // (at least one window)
+							w = end < (u32)WK_FBW - 1u ? end : (u32)WK_FBW - 1u;
+						}
+					}
+					items[at++] = make_uint2(g | (sgm << 24) | (m << 28), first | (end << 16));
+					first = end;
+				}
 			}
 		}
-	}
-	if (g < nb) {
-		uint4 *z = reinterpret_cast<uint4 *>(f);
+		if (g < nb) {
+			uint4 *z = reinterpret_cast<uint4 *>(f);
 #pragma unroll
-		for (int q = 0; q < WK_FBW / 16; q++)
-			z[q] = make_uint4(0u, 0u, 0u, 0u);
+			for (int q = 0; q < WK_FBW / 16; q++)
+				z[q] = make_uint4(0u, 0u, 0u, 0u);
+		}
+		jobs_all += jobs;
 	}
-	u32 sum = jobs;
+	u32 sum = jobs_all;
 #pragma unroll
 	for (int m = 32; m >= 1; m >>= 1)
 		sum += (u32)__shfl_xor((int)sum, m);
@@ -822,8 +880,8 @@ int ugrt_dda_split_state(ugrt_ctx *ctx, u32 RPW, u32 total_refs, WalkSplit *sp, 
 		return UGRT_OK;
 	const size_t npix = (size_t)ctx->npix, maxg = (npix + 63) / 64 * (64 / RPW) + 64 / RPW, nchunk = (npix + 63) / 64 + 1;
 	// three header blocks in turn (this launch's, the one before, the one after), two `walked` arrays in turn
-	const size_t o_items = 3 * 64, o_fb = o_items + maxg * WK_MAXSEG * sizeof(uint2), o_done = o_fb + maxg * WK_FBW,
-		     o_cut = o_done + maxg * 4, o_chunk = (o_cut + maxg + 15) / 16 * 16, o_key = (o_chunk + nchunk * 4 + 15) / 16 * 16,
+	const size_t o_items = 3 * 64, o_fb = o_items + maxg * WK_MAXSEG * sizeof(uint2), o_done = o_fb + maxg * WK_FBW + 16,
+		     o_cut = o_done + maxg * 4 + 16, o_chunk = (o_cut + maxg + 15) / 16 * 16, o_key = (o_chunk + nchunk * 4 + 15) / 16 * 16,
 		     o_tend = o_key + npix * 8, o_texam = o_tend + npix * 4, o_walked = o_texam + npix * 4, bytes = o_walked + 2 * npix * 4;
 	const void *before = ctx->dsplit.p;
 	int rc = ugrt_buf_reserve(ctx, ctx->dsplit, bytes);
@@ -870,8 +928,9 @@ int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list,
 {
 	u32 *ticket = ctx->d_small + UGRT_DSMALL_TICKET;
 	if (sp.items) {
-		hipLaunchKernelGGL(k_dda_segments, dim3((sph.maxg + SEG_THREADS - 1) / SEG_THREADS), dim3(SEG_THREADS), 0, ctx->stream, list,
-				   dcount, RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg);
+		const u32 sblocks = (sph.maxg + SEG_THREADS - 1) / SEG_THREADS;
+		hipLaunchKernelGGL(k_dda_segments, dim3(sblocks < 64u ? sblocks : 64u), dim3(SEG_THREADS), 0, ctx->stream, list,
+				   dcount, RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg, (u32)blocks);
 		UGRT_HIP(hipGetLastError());
 	}
 #define WK_LAUNCH(CNTV, RECV)                                                                                          \

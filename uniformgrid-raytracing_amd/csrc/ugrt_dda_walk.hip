@@ -633,9 +633,10 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 			// position) over the segments' closest hits: a hit found further along the walk with a smaller t lies in an
 			// earlier cell, whose list holds its triangle too.  It is valid if its t is not beyond the exit of the last
 			// cell that was looked at (the segments' windows join up) or the ray has left the grid.  Otherwise - the ray
-			// goes further than the last time - and where the argument rests on the lists alone - the winner was found by
-			// a later segment BEHIND the entry of its cell - the ray is walked again in one piece.  The last segment to
-			// finish writes the group's results.
+			// goes further than the last time - the wave that does the merge takes the ray up from there (`redo`, at the
+			// top of the loop), and where the argument rests on the lists alone - the winner was found by a later segment
+			// BEHIND the entry of its cell - it walks the ray afresh.  The last segment to finish writes the group's
+			// results.
 			// (a ray that still walks where the segment ends, and went no further the last time, ends here: no later
 			// segment has it)
 			if (walking && widx >= wprev)
@@ -728,14 +729,14 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 	} // work items
 }
 
-// The cut groups of the launch that follows (one thread per group): a group whose jobs in the LAST launch of the same
-// ray list (same number of rays, same rays per wave: the history in sp.fb) came to more than LOAD percent of the average
-// group's, and to more than one of the launch's WAVES' share of all jobs, is cut into up to WK_MAXSEG segments of windows
-// with about equal jobs.  FORCE >= 2 cuts every group into that
-// many segments of three windows (tests).  Also clears the history for the launch that follows, and sets up the merge
-// state of the cut groups' rays.  hdr_prev / hdr_next: the header words of the launch before / after this one.
+// The cut groups of the launch that follows (one thread per group): a group whose jobs in the context's LAST bounce (the
+// history in sp.fb, kept under spans of pixels: it need not have been the same rays) came to more than LOAD percent of
+// the average group's, and to more than one of the launch's WAVES' share of all jobs, is cut into up to WK_MAXSEG
+// segments of windows with about equal jobs.  FORCE >= 2 cuts every group into that many segments of three windows
+// (tests).  Also clears the history for the launch that follows.  hdr_prev / hdr_next: the header words of the launch
+// before / after this one.
 #define SEG_THREADS 256
-__global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restrict__ list, const u32 *__restrict__ count_p, u32 RPW,
+__global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restrict__ count_p, u32 RPW,
 							      WalkSplit sp, uint2 *__restrict__ items, unsigned char *__restrict__ cut,
 							      const u32 *__restrict__ hdr_prev, u32 *__restrict__ hdr_next, u32 LOAD, u32 FORCE,
 							      u32 maxg, u32 WAVES)
@@ -929,8 +930,8 @@ int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list,
 	u32 *ticket = ctx->d_small + UGRT_DSMALL_TICKET;
 	if (sp.items) {
 		const u32 sblocks = (sph.maxg + SEG_THREADS - 1) / SEG_THREADS;
-		hipLaunchKernelGGL(k_dda_segments, dim3(sblocks < 64u ? sblocks : 64u), dim3(SEG_THREADS), 0, ctx->stream, list,
-				   dcount, RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg, (u32)blocks);
+		hipLaunchKernelGGL(k_dda_segments, dim3(sblocks < 64u ? sblocks : 64u), dim3(SEG_THREADS), 0, ctx->stream, dcount,
+				   RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg, (u32)blocks);
 		UGRT_HIP(hipGetLastError());
 	}
 #define WK_LAUNCH(CNTV, RECV)                                                                                          \

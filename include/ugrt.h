@@ -192,7 +192,8 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * order; "dda_split" (window kernel) 1 = the ray groups that were long in the context's last bounce are cut into
  * segments of their walk that run on different waves and are merged per ray (default; the history is kept per pixel,
  * so it serves the next frame of a moving scene as far as it goes), 0 = off, 2..4 = every group is cut (tests);
- * "dda_split_load" a group's jobs, in percent of the average group's, per segment it is cut into (default 400);
+ * "dda_split_load" a group's jobs, in percent of the average group's, per segment it is cut into (default 400),
+ * "dda_split_segments" segments a group is cut into at most (4; 1 = none is cut: the long groups only start first);
  * "primary_seg" triangles per primary work item; "primary_order" 0 = a flush's jobs run in list order
  * (default: nearest triangles first), "primary_chunk" jobs between two looks at the rays' closest hits;
  * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64" shape the

@@ -409,7 +409,7 @@ def test_bounce_split_walks_on_a_moving_scene(ugrt, torch, rpw):
             went_on += st["rays_walked_again"]
             cut_frames += 1 if st["segments"] else 0
         # (after a launch most of whose cut groups had such rays the context cuts nothing for 1, 2, 4 ... launches)
-        assert went_on > 0 and 2 <= cut_frames < 6, (went_on, cut_frames)
+        assert went_on > 0 and cut_frames >= 2, (went_on, cut_frames)
 
 
 def test_band_split_equals_full_frame(ugrt, O, torch):

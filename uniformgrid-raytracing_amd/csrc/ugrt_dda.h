@@ -34,7 +34,7 @@ struct WalkSplitHost {
 	unsigned char *cut;
 	const u32 *hdr_prev;
 	u32 *hdr_next;
-	u32 load, force, maxg;
+	u32 load, force, maxg, maxseg;
 };
 
 // what a group's history is kept under: the list is made of chunks of 64 entries that belong to one span of pixels

@@ -739,7 +739,7 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 __global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restrict__ count_p, u32 RPW,
 							      WalkSplit sp, uint2 *__restrict__ items, unsigned char *__restrict__ cut,
 							      const u32 *__restrict__ hdr_prev, u32 *__restrict__ hdr_next, u32 LOAD, u32 FORCE,
-							      u32 maxg, u32 WAVES)
+							      u32 maxg, u32 WAVES, u32 MAXSEG)
 {
 	__shared__ u32 s_red[SEG_THREADS / 64];
 	const u32 t = threadIdx.x;
@@ -785,6 +785,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restr
 	for (u32 g0 = blockIdx.x * SEG_THREADS; g0 < nb; g0 += gridDim.x * SEG_THREADS) {
 		const u32 g = g0 + t;
 		u32 jobs = 0u, m = 0u;
+		bool early = false;
 		u32 fw[WK_FBW];
 		unsigned char *f = nullptr;
 		if (g < nb) {
@@ -802,12 +803,15 @@ __global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restr
 			for (int w = 0; w < WK_FBW; w++)
 				jobs += fw[w];
 			m = FORCE >= 2u ? FORCE : (valid ? (jobs + limit - 1u) / limit : 1u);
-			m = m < 1u ? 1u : (m > (u32)WK_MAXSEG ? (u32)WK_MAXSEG : m);
-			cut[g] = m > 1u ? 1 : 0;
+			m = m < 1u ? 1u : (m > MAXSEG ? MAXSEG : m);
+			// a group with more than a third of the jobs that would get it cut is listed too, whole: the long groups start
+			// first, whatever their place in the list of rays
+			early = m == 1u && valid && jobs * 3u > limit;
+			cut[g] = (m > 1u || early) ? 1 : 0;
 		}
 		// places in the list: one atomic per wave (a few hundred groups are cut: one each would be ~6 us on one word)
 		{
-			const u32 mine = m > 1u ? m : 0u;
+			const u32 mine = m > 1u ? m : (early ? 1u : 0u);
 			u32 incl = mine;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
@@ -820,10 +824,12 @@ __global__ __launch_bounds__(SEG_THREADS) void k_dda_segments(const u32 *__restr
 			if (wave_total != 0u) {
 				if ((t & 63u) == 0u) {
 					base = atomicAdd(&sp.hdr[2], wave_total);
-					atomicAdd(&sp.hdr[6], (u32)__popcll(__ballot(mine != 0u))); // (groups cut)
+					atomicAdd(&sp.hdr[6], (u32)__popcll(__ballot(mine > 1u))); // (groups cut)
 				}
 				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
 			}
+			if (early)
+				items[base + incl - mine] = make_uint2(g | (1u << 28), 0xFFFFu << 16);
 			if (m > 1u) {
 				u32 at = base + incl - mine;
 				// segment s ends before the first window by which (s + 1) / m of the jobs have been seen
@@ -917,6 +923,8 @@ int ugrt_dda_split_state(ugrt_ctx *ctx, u32 RPW, u32 total_refs, WalkSplit *sp, 
 	sph->hdr_next = (u32 *)(b + 64 * ((turn + 1u) % 3u));
 	sph->load = ctx->opt[UGRT_OPT_DDA_SPLIT_LOAD] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_SPLIT_LOAD] : 400u;
 	sph->force = mode >= 2 ? (u32)mode : 0u;
+	sph->maxseg = mode >= 2 ? (u32)WK_MAXSEG
+			       : (ctx->opt[UGRT_OPT_DDA_SPLIT_SEGMENTS] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_SPLIT_SEGMENTS] : (u32)WK_MAXSEG);
 	sph->maxg = (u32)maxg;
 	return UGRT_OK;
 }
@@ -931,7 +939,7 @@ int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list,
 	if (sp.items) {
 		const u32 sblocks = (sph.maxg + SEG_THREADS - 1) / SEG_THREADS;
 		hipLaunchKernelGGL(k_dda_segments, dim3(sblocks < 64u ? sblocks : 64u), dim3(SEG_THREADS), 0, ctx->stream, dcount,
-				   RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg, (u32)blocks);
+				   RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg, (u32)blocks, sph.maxseg);
 		UGRT_HIP(hipGetLastError());
 	}
 #define WK_LAUNCH(CNTV, RECV)                                                                                          \

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 						       const float *__restrict__ verts, const int *__restrict__ tris,
 						       const float4 *__restrict__ rec, PrimaryOut out,
 						       u64 *__restrict__ best, int p0, unsigned long long *__restrict__ counters,
-						       u32 ORDER, u32 CHUNK)
+						       u32 ORDER, u32 CHUNK, u32 SLICES)
 {
 	__shared__ __attribute__((aligned(16))) float lds[SURV_CAP * TRI_STRIDE];
 	__shared__ unsigned short jobs[JOB_CAP]; // survivor slot | lane offset of the quadrant << 7
@@ -197,7 +197,16 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 	const u32 nitems = *nitems_p;
 	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
 	unsigned long long ps[PS_END] = { 0 };
-	for (u32 it = d_xcd_block(); it < nitems; it += gridDim.x) {
+	// SLICES 1: persistent waves, a contiguous slice of the list per XCD; otherwise one wave per item, runs of SLICES >> 1
+	// items per XCD in turn (workgroup b runs on XCD b % 8)
+	u32 first = blockIdx.x;
+	if (SLICES == 1u) {
+		first = d_xcd_block();
+	} else if (SLICES > 1u) {
+		const u32 run = SLICES >> 1, j = blockIdx.x >> 3;
+		first = ((j / run) * 8u + (blockIdx.x & 7u)) * run + j % run;
+	}
+	for (u32 it = first; it < nitems; it += gridDim.x) {
 		const WItem w = items[it];
 		if (COUNT) {
 			ps[PS_ITEMS]++;
@@ -671,10 +680,22 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 	UGRT_HIP(hipGetLastError());
 	PrimaryOut out = { d_normal, d_t_value, d_ray_dir, d_shadowed, d_intersect_id };
-	// twice the waves of the other persistent kernels: 19 of these waves fit a CU (LDS), so the chip holds 4864 of
-	// them and the rest start as slots free up -- the finer the shares, the better the dispatcher evens out tiles
-	// of unequal cost (alone on the chip: 0.41 ms with 8192 waves, 0.35 ms with 16384, 0.41 ms with 20480)
-	const int pwaves = launch_blocks_for((u32)cap, ctx->opt[UGRT_OPT_PRIMARY_WAVES] > 0 ? ctx->opt[UGRT_OPT_PRIMARY_WAVES] : 16384);
+	// One wave per work item, in list order: the dispatcher then evens out items of unequal cost by itself.  (Round 2
+	// gave 16384 persistent waves two items each, in contiguous slices of the list per XCD for the sake of its L2: 0.305
+	// ms alone on the 1 M-triangle frame, with a tail of long second items and of the XCD that holds the heavy screen
+	// region - profiles/r03_primary_timeline.txt.  One item per wave in those slices 0.349, two per wave dealt item by
+	// item over the XCDs 0.326, one per wave so dealt 0.254; profiles/r03_primary_waves.txt.)  "primary_waves" restores the
+	// persistent form with that many waves.
+	const bool p_slices = ctx->opt[UGRT_OPT_PRIMARY_WAVES] > 0;
+	// (what an XCD gets are runs of `p_run` neighbouring items - neighbours share triangles and the XCD's L2 -, run r
+	// going to XCD r % 8; 0 = item i to XCD i % 8.  128: the 1 M-triangle frame is indifferent up to 256 (0.254-0.258
+	// ms, 0.278 at 1024), the 79 k-triangle hall, whose items cost the same, likes them long (0.126 at 0-32, 0.119 at
+	// 128, 0.115 at 2048, 0.113 in the slices))
+	const u32 p_run = ctx->opt[UGRT_OPT_PRIMARY_XCD_RUN] >= 0 ? (u32)ctx->opt[UGRT_OPT_PRIMARY_XCD_RUN] : 128u;
+	size_t one_each = cap;
+	if (p_run)
+		one_each = (cap + 8u * p_run - 1) / (8u * p_run) * (8u * p_run); // (a whole number of rounds of runs: the mapping is a permutation)
+	const int pwaves = p_slices ? launch_blocks_for((u32)cap, ctx->opt[UGRT_OPT_PRIMARY_WAVES]) : (int)(one_each < 0x7FFFFFFFu ? one_each : 0x7FFFFFFFu);
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_PRIMARY);
 	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
 	const bool counting = (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) != 0;
@@ -686,7 +707,7 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 #define LAUNCH_PRIMARY(REC_, COUNT_)                                                                                  \
 	hipLaunchKernelGGL((k_trace_primary<REC_, COUNT_>), dim3(pwaves), dim3(64), 0, st, ctx->cam, tex,              \
 			   (const WItem *)items, (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist, \
-			   (const float4 *)(REC_ ? ctx->trirec.p : nullptr), out, (u64 *)ctx->best.p, ctx->p0, pc, p_order, p_chunk)
+			   (const float4 *)(REC_ ? ctx->trirec.p : nullptr), out, (u64 *)ctx->best.p, ctx->p0, pc, p_order, p_chunk, p_slices ? 1u : p_run << 1)
 	if (counting) {
 		UGRT_HIP(hipMemsetAsync(pc, 0, UGRT_PRIMARY_STATS * 8, st));
 		if (use_rec)

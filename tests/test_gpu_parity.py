@@ -200,7 +200,8 @@ def test_reflection_bounce(ugrt, O, torch, name, cam, W, H):
 
 @pytest.mark.parametrize("name,W,H,ud", [("crash", 256, 144, (32, 32, 16)), ("crash", 320, 200, (64, 64, 32)),
                                          ("hall", 256, 256, (16, 16, 8)), ("cornell", 128, 128, (8, 8, 8)),
-                                         ("cornell", 128, 128, (33, 17, 5)), ("cornell", 96, 64, (3, 1000, 2))])
+                                         ("cornell", 128, 128, (33, 17, 5)), ("cornell", 96, 64, (3, 1000, 2)),
+                                         ("cornell", 72, 40, (8, 8, 8))])  # (the last: a band that ends inside a 512-pixel span of the ray list)
 def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
     """The three bounce kernels (0 window kernel, 1 per-ray, 2 beam kernel of round 2) at every launch shape, with
     and without the (entry cell, octant) ray sort: hit ids equal, t bit-equal to the oracle; the counting variants

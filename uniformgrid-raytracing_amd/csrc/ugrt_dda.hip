@@ -733,7 +733,10 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		g.dims[k] = G.dims[k];
 	}
 	int rc;
-	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, (size_t)ctx->npix * 4)))
+	// (k_dda_prepare pads every span of DDA_PREP_SPAN pixels to whole chunks of 64 list entries: the list can be that
+	// much longer than the band has pixels when the band is not a whole number of spans)
+	const size_t list_cap = ((size_t)ctx->npix + DDA_PREP_SPAN - 1) / DDA_PREP_SPAN * DDA_PREP_SPAN;
+	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, list_cap * 4)))
 		return rc;
 	u32 *list = (u32 *)ctx->wscan.p, *dcount = ctx->d_small + UGRT_DSMALL_DDA_RAYS;
 	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
@@ -784,7 +787,7 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		blocks = ctx->opt[UGRT_OPT_DDA_BLOCKS];
 	// option dda_sort (SURVEY 8f.2 as written): the list sorted by (entry cell, octant) with the frame's pair sort
 	if (ctx->opt[UGRT_OPT_DDA_SORT] == 1) {
-		const u32 cap = (u32)ctx->npix;
+		const u32 cap = (u32)list_cap;
 		if ((rc = ugrt_buf_reserve(ctx, ctx->dsort, (size_t)cap * 12)))
 			return rc;
 		u32 *k0 = (u32 *)ctx->dsort.p, *k1 = k0 + cap, *l1 = k1 + cap;

@@ -885,7 +885,8 @@ int ugrt_dda_split_state(ugrt_ctx *ctx, u32 RPW, u32 total_refs, WalkSplit *sp, 
 	const int mode = ctx->opt[UGRT_OPT_DDA_SPLIT] >= 0 ? ctx->opt[UGRT_OPT_DDA_SPLIT] : 1;
 	if (mode == 0 || RPW < 16u || (64u % RPW) != 0u || total_refs >= (1u << 28))
 		return UGRT_OK;
-	const size_t npix = (size_t)ctx->npix, maxg = (npix + 63) / 64 * (64 / RPW) + 64 / RPW, nchunk = (npix + 63) / 64 + 1;
+	// (groups and chunks of the padded list: a whole number of 512-pixel spans, ugrt_dda.hip)
+	const size_t npix = (size_t)ctx->npix, slots = (npix + 511) / 512 * 512, maxg = slots / 64 * (64 / RPW) + 64 / RPW, nchunk = slots / 64 + 1;
 	// three header blocks in turn (this launch's, the one before, the one after), two `walked` arrays in turn
 	const size_t o_items = 3 * 64, o_fb = o_items + maxg * WK_MAXSEG * sizeof(uint2), o_done = o_fb + maxg * WK_FBW + 16,
 		     o_cut = o_done + maxg * 4 + 16, o_chunk = (o_cut + maxg + 15) / 16 * 16, o_key = (o_chunk + nchunk * 4 + 15) / 16 * 16,

@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 DDA_WAVES_THROUGHPUT, DDA_WAVES_ONE_FRAME = 3072, 1024
 DDA_RPW_THROUGHPUT = 64
 DDA_SPLIT_THROUGHPUT = 0  # split walks of the bounce (ugrt.h "dda_split"): off beside other frames, on (the default) alone
-SHADOW_WAVES_THROUGHPUT = 4096
+SHADOW_WAVES_THROUGHPUT = 8192  # (the cull pass; round 2: 4096.  The exact pass runs one wave per work item since round 3)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -342,8 +342,8 @@ def main():
             # the bounce's persistent waves: with several frames in flight every ray group gets a wave of its own (the
             # chip holds 3072 of them: 1.37 -> 1.33 ms); a renderer on its own caps them at 1024 so that a sort pass of
             # its main stream finds room (its default, which the one-frame latency below is measured with)
-            # The two shadow kernels the other way round: alone they are fastest on 8192 waves (their default), beside
-            # three other frames on 4096 (1.35 -> 1.31 ms): the chip is shared.
+            # The shadow cull pass: 8192 persistent waves (its default) beside other frames too (round 2 ran both shadow
+            # kernels on 4096 there; with the exact pass on one wave per item: 1.168 ms on 4096, 1.159 on 8192).
             if rr.aux is not None and args.frames_in_flight > 1:
                 rr.aux.set_option("dda_blocks", DDA_WAVES_THROUGHPUT)
                 rr.ctx.set_option("shadow_waves", SHADOW_WAVES_THROUGHPUT)

@@ -201,8 +201,9 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * one, "sort_items" 8 / 16 pairs per thread of a radix pass (default: by size), "sort_fused_hist" 1 = the kernels
  * that write sort keys count their digits (measured slower: DESIGN.md section 8); "dda_blocks", "primary_waves",
  * "shadow_waves": number of persistent single-wave workgroups of the bounce, the primary tracer and the two
- * shadow kernels (the primary tracer's default is one wave per work item, "primary_xcd_run" neighbouring items per
- * XCD in turn).
+ * shadow kernels (the primary tracer and the exact shadow pass run one wave per work item by default, "primary_xcd_run" /
+ * "shadow_xcd_run" neighbouring items per XCD in turn; "primary_waves" set / "shadow_xcd_run" 0 restore their persistent
+ * forms; "shadow_waves" is always the cull pass's).
  * "async_build" 1: the grid builds and ugrt_trace_shadow stop waiting for the device.  The reference reads
  * total_triangles back to size its lists (frustum_grid.h:254); here the second and later builds of a grid size
  * buffers and launches by what the build before needed plus a quarter, every kernel takes the real counts from

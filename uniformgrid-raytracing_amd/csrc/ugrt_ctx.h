@@ -46,6 +46,7 @@ enum {
 	UGRT_OPT_DDA_SPLIT_LOAD,   // "dda_split_load": jobs of a group, in percent of the average group's, per segment it is cut into (default 400)
 	UGRT_OPT_DDA_SPLIT_SEGMENTS, // "dda_split_segments": segments a group is cut into at most (1..4; 1 = none is cut, the long groups are only started first)
 	UGRT_OPT_PRIMARY_XCD_RUN,  // "primary_xcd_run": primary tracer, one wave per item: neighbouring items per XCD in turn (default 128; 0 = one)
+	UGRT_OPT_SHADOW_XCD_RUN,   // "shadow_xcd_run": exact shadow pass: one wave per item, this many neighbouring items per XCD in turn (default 128); 0 = the persistent waves of round 2
 	UGRT_OPT_COUNT
 };
 

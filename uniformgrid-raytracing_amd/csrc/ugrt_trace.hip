@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      const float *__restrict__ cmPt, u32 XSEG, u32 *__restrict__ sub_done,
 						      u32 nsubmax, const float4 *__restrict__ sray, u32 item_cap,
 						      u32 *__restrict__ report, const u32 *__restrict__ status,
-						      const unsigned long long *__restrict__ work)
+						      const unsigned long long *__restrict__ work, u32 SLICES)
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
 	const int lane = threadIdx.x;
@@ -1460,7 +1460,16 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 	if (total > item_cap)
 		total = item_cap; // (asynchronous form: a list cut at its estimated capacity is flagged by k_pair_items)
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
-	for (u32 it = d_xcd_block(); it < total; it += gridDim.x) {
+	// SLICES 1: persistent waves, a contiguous slice of the list per XCD; otherwise one wave per item, runs of SLICES >> 1
+	// items per XCD in turn (as the primary tracer)
+	u32 first = blockIdx.x;
+	if (SLICES == 1u) {
+		first = d_xcd_block();
+	} else if (SLICES > 1u) {
+		const u32 run = SLICES >> 1, j = blockIdx.x >> 3;
+		first = ((j / run) * 8u + (blockIdx.x & 7u)) * run + j % run;
+	}
+	for (u32 it = first; it < total; it += gridDim.x) {
 		const u32 sgm = item_seg[it], gs = item_sub[it];
 		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list
 		const GBox bx = boxes[g];
@@ -1863,18 +1872,27 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	// 4. exact pass
 	ugrt_prof_begin(ctx, UGRT_ST_TRACE_SHADOW);
+	// One wave per item, runs of `x_run` neighbouring items per XCD in turn (as the primary tracer; alone 0.254 -> 0.216
+	// ms, profiles/r03_shadow_waves.txt); "shadow_xcd_run" 0 restores round 2's persistent waves ("shadow_waves" of
+	// them, which the cull pass always runs on) with a contiguous slice of the list per XCD
+	const int x_opt = ctx->opt[UGRT_OPT_SHADOW_XCD_RUN];
+	const bool x_persistent = x_opt == 0;
+	const u32 x_run = x_opt > 0 ? (u32)x_opt : 128u;
+	const u32 xwaves = x_persistent ? (u32)launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])
+					: (u32)(((size_t)xcap + 8u * x_run - 1) / (8u * x_run) * (8u * x_run));
+	const u32 xslices = x_persistent ? 1u : x_run << 1;
 	if (use_rec)
-		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam,
+		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(xwaves), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt);
+				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt, xslices);
 	else
-		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam,
+		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(xwaves), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt);
+				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt, xslices);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	// ONE copy per pass: {pairs, beams} as found (asynchronous form: what the next pass is sized by; the waiting form

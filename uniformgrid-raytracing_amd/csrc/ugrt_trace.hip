@@ -1456,9 +1456,11 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		reinterpret_cast<unsigned long long *>(report + 4)[0] = work[0];
 		reinterpret_cast<unsigned long long *>(report + 4)[1] = work[1];
 	}
-	u32 total = xincl[G - 1];
-	if (total > item_cap)
-		total = item_cap; // (asynchronous form: a list cut at its estimated capacity is flagged by k_pair_items)
+	// (the list is written, and sorted, at its capacity: behind the last item come entries of segment XSEG_LAST + 1.  A
+	// wave tells by its entry that there is nothing to do - not by the number of items, a load every one of the 400 k
+	// single-item waves would have to wait for first.  Asynchronous form: a list cut at its estimated capacity is
+	// flagged by k_pair_items.)
+	const u32 total = item_cap;
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
 	// SLICES 1: persistent waves, a contiguous slice of the list per XCD; otherwise one wave per item, runs of SLICES >> 1
 	// items per XCD in turn (as the primary tracer)
@@ -1471,6 +1473,8 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 	}
 	for (u32 it = first; it < total; it += gridDim.x) {
 		const u32 sgm = item_seg[it], gs = item_sub[it];
+		if (sgm > XSEG_LAST)
+			continue;
 		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list
 		const GBox bx = boxes[g];
 		const u32 p0 = pstart[g] + sgm * XSEG;

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define UGRT_VERSION 103
+#define UGRT_VERSION 104
 
 enum {
 	UGRT_OK = 0,
@@ -198,7 +198,8 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * (default: nearest triangles first), "primary_chunk" jobs between two looks at the rays' closest hits;
  * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64" shape the
  * shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix sort instead of the built-in
- * one, "sort_items" 8 / 16 pairs per thread of a radix pass (default: by size), "sort_fused_hist" 1 = the kernels
+ * one, "sort_items" 8 / 16 pairs per thread of a radix pass (default: by size), "sort_rank" 0 = the passes rank by
+ * ballots instead of LDS atomics, "sort_fused_hist" 1 = the kernels
  * that write sort keys count their digits (measured slower: DESIGN.md section 8); "dda_blocks", "primary_waves",
  * "shadow_waves": number of persistent single-wave workgroups of the bounce, the primary tracer and the two
  * shadow kernels (the primary tracer and the exact shadow pass run one wave per work item by default, "primary_xcd_run" /
@@ -212,6 +213,11 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * incomplete) and the next calls run in the waiting form again, which sizes everything exactly.
  * ugrt_grid_info.total_refs of such a build is final once the stream has been synchronised. */
 int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value);
+/* counters and findings of this context (no reference counterpart; the bench line and the tests read them):
+ * "radix_launches" histogram + pass kernels of the built-in radix sort enqueued so far, "sort_rank_atomic" 1 = the radix passes rank by LDS
+ * atomics (the context's self-test found them served in lane order on this device), 0 = by ballots, -1 = no sort
+ * has run yet.  Unknown key: UGRT_EINVAL. */
+int ugrt_ctx_get_state(ugrt_ctx *ctx, const char *key, long long *value);
 int ugrt_ctx_synchronize(ugrt_ctx *ctx);
 void ugrt_ctx_destroy(ugrt_ctx *ctx);
 

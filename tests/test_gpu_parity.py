@@ -639,8 +639,10 @@ def test_radix_sort_is_the_stable_sort(ugrt, torch, n, bits, kind):
     dk, dv = ctx.upload(keys.view(np.int32)), ctx.upload(vals.view(np.int32))
     mask = np.uint32((1 << bits) - 1) if bits < 32 else np.uint32(0xFFFFFFFF)
     order = np.argsort(keys & mask, kind="stable")
-    for library, items in ((False, -1), (False, 8), (False, 16), (True, -1)):  # items: pairs per thread of a pass
+    # items: pairs per thread of a pass; rank: 0 = ranks by ballots, -1 = by LDS atomics where the context's self-test allows
+    for library, items, rank in ((False, -1, -1), (False, 8, -1), (False, 16, -1), (False, 8, 0), (False, 16, 0), (True, -1, -1)):
         ctx.set_option("sort_items", items)
+        ctx.set_option("sort_rank", rank)
         for rep in range(2):  # twice: the sort's state (tickets, histogram rows) must be clean again after a sort
             ok, ov = torch.empty_like(dk), torch.empty_like(dv)
             ctx.sort_pairs(dk, ok, dv, ov, bits, library=library)
@@ -648,6 +650,12 @@ def test_radix_sort_is_the_stable_sort(ugrt, torch, n, bits, kind):
             np.testing.assert_array_equal(u32(ok), keys[order])
             np.testing.assert_array_equal(u32(ov), vals[order])
             np.testing.assert_array_equal(u32(dk), keys)  # inputs untouched
+        if not library:
+            assert ctx.get_state("sort_rank_atomic") == (0 if rank == 0 else ctx.get_state("sort_rank_atomic"))
+    # the self-test has run with the first sort; on gfx950 the LDS serves equal addresses in lane order
+    ctx.set_option("sort_rank", -1)
+    assert ctx.get_state("sort_rank_atomic") == 1, "k_rs_selftest: LDS atomics not in lane order on this device (ballot ranks are used)"
+    assert ctx.get_state("radix_launches") > 0
 
 
 def test_known_answers_on_gpu(ugrt, torch):

@@ -119,6 +119,7 @@ PROTOTYPES = {
     "ugrt_ctx_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(Config)]),
     "ugrt_ctx_set_stream": (C.c_int, [_P, _P]),
     "ugrt_ctx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "ugrt_ctx_get_state": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_longlong)]),
     "ugrt_ctx_synchronize": (C.c_int, [_P]),
     "ugrt_ctx_destroy": (None, [_P]),
     "ugrt_upload_camera": (C.c_int, [_P, _F3]),

@@ -196,7 +196,21 @@ static const struct {
 	{ "async_build", 0, 1 },        { "primary_waves", 64, 1 << 20 },
 	{ "shadow_waves", 64, 1 << 20 }, { "dda_sort", 0, 1 }, { "sort_fused_hist", 0, 1 }, { "primary_order", 0, 1 }, { "primary_chunk", 4, 64 }, { "sort_items", 8, 16 }, { "dda_cull_work", 1, 1 << 30 },
 	{ "dda_split", 0, 4 }, { "dda_split_load", 50, 100000 }, { "dda_split_segments", 1, 4 }, { "primary_xcd_run", 0, 4096 }, { "shadow_xcd_run", 0, 4096 },
+	{ "sort_rank", 0, 1 },
 };
+
+extern "C" int ugrt_ctx_get_state(ugrt_ctx *ctx, const char *key, long long *value)
+{
+	if (!ctx || !key || !value)
+		return ugrt_fail(UGRT_EINVAL, "ctx_get_state: null argument");
+	if (strcmp(key, "radix_launches") == 0)
+		*value = (long long)ctx->rs_launches;
+	else if (strcmp(key, "sort_rank_atomic") == 0)
+		*value = ctx->rs_atomic_rank < 0 ? -1 : (ctx->rs_atomic_rank == 1 && ctx->opt[UGRT_OPT_SORT_RANK] != 0 ? 1 : 0);
+	else
+		return ugrt_fail(UGRT_EINVAL, "ctx_get_state: unknown key '%s'", key);
+	return UGRT_OK;
+}
 
 extern "C" int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value)
 {

@@ -47,6 +47,7 @@ enum {
 	UGRT_OPT_DDA_SPLIT_SEGMENTS, // "dda_split_segments": segments a group is cut into at most (1..4; 1 = none is cut, the long groups are only started first)
 	UGRT_OPT_PRIMARY_XCD_RUN,  // "primary_xcd_run": primary tracer, one wave per item: neighbouring items per XCD in turn (default 128; 0 = one)
 	UGRT_OPT_SHADOW_XCD_RUN,   // "shadow_xcd_run": exact shadow pass: one wave per item, this many neighbouring items per XCD in turn (default 128); 0 = the persistent waves of round 2
+	UGRT_OPT_SORT_RANK,        // "sort_rank": radix pass: 0 = ranks by ballots, 1 / default = by LDS atomics where the device's self-test allows it
 	UGRT_OPT_COUNT
 };
 
@@ -131,6 +132,8 @@ struct ugrt_ctx {
 	u32 scan_epoch = 0;           // tag of the last scan's state words
 	DevBuf rs_state, rs_tmp[2];   // own radix sort: per-site histogram rows + tickets, look-back words; ping-pong buffers
 	u32 rs_epoch = 0;             // tag of the last pass's look-back words
+	unsigned long long rs_launches = 0; // histogram + pass kernels enqueued so far (ugrt_ctx_get_state "radix_launches")
+	int rs_atomic_rank = -1;      // k_rs_selftest: 1 = LDS add-with-return serves equal addresses in lane order on this device
 	bool rs_dirty[8] = { false }; // per sort site: a producer was handed the histogram rows and its sort has not run yet
 	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
 	// gather ONE record per reference instead of 3 indices + 3 vertices

@@ -109,8 +109,127 @@ __device__ __forceinline__ u32 d_rs_wait_sum(const u64w *row, u32 count, u32 str
 	return sum;
 }
 
+// Rank of every pair among the pairs of its digit inside its wave's 64 * RS_ITEMS pairs, in memory order, and the
+// wave's digit counts in cnt[].  Two forms:
+//   ATOMIC: one ds_add_rtn_u32 per pair on the wave's counter of its digit.  A wave's LDS instructions execute in
+//     program order, and inside one instruction the lanes that hit the same counter are served in lane order (the
+//     hardware's conflict resolution: lowest lane first) -- that order is not in the ISA manual, so every context
+//     checks it on its device before it uses this form (k_rs_selftest; "sort_rank" 0 forces the other form);
+//   ballots: the lanes of a pair's digit group are found with one ballot per digit bit (on 32-bit halves: one
+//     v_bitop3 per half and bit), the group's first lane bumps the counter.
+// 3 vector instructions a pair against ~45 (round 3's form: ~79, more than half of the kernel's 2000 per wave and tile).
+template <int RS_ITEMS, bool ATOMIC, bool FULL>
+__device__ __forceinline__ void d_rs_rank(const u32 (&k)[RS_ITEMS], u32 (&r)[RS_ITEMS], u32 *cnt, u32 shift, u32 dmask, u32 first, u32 n,
+					  u32 lane)
+{
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++) {
+		const bool ok = FULL || first + (u32)i * 64u + lane < n;
+		const u32 d = (k[i] >> shift) & dmask;
+		if (ATOMIC) {
+			r[i] = 0;
+			if (ok)
+				r[i] = atomicAdd(&cnt[d], 1u);
+		} else {
+			const unsigned long long act = FULL ? ~0ull : __ballot(ok);
+			u32 glo = (u32)act, ghi = (u32)(act >> 32);
+#pragma unroll
+			for (int b = 0; b < 8; b++) {
+				const u32 sb = (u32)((int)(d << (31 - b)) >> 31); // all ones where the bit is set
+				const unsigned long long m = __ballot(sb != 0u);
+				glo &= ~((u32)m ^ sb); // lanes whose bit equals this lane's
+				ghi &= ~((u32)(m >> 32) ^ sb);
+			}
+			const u32 before = __builtin_amdgcn_mbcnt_hi(ghi, __builtin_amdgcn_mbcnt_lo(glo, 0u)); // group lanes below this one
+			volatile u32 *vc = cnt;
+			u32 old = 0;
+			if (ok)
+				old = vc[d];
+			r[i] = old + before;
+			__builtin_amdgcn_wave_barrier(); // every lane of the group has read the counter
+			if (ok && before == 0u)
+				vc[d] = old + (u32)__popc(glo) + (u32)__popc(ghi);
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+}
+
+// the work of one tile that holds pairs: keys and values in, ranks, offsets (look-back), LDS reorder, scatter
+template <int RS_ITEMS, bool ATOMIC, bool FULL>
+__device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
+					  u32 *__restrict__ vout, u32 n, u32 shift, u32 dmask, const u32 *hist, u64w *look, u64w *look2,
+					  u32 epoch, u32 tile, u32 *s_keys, u32 *s_vals, u32 (*s_cnt)[RS_BINS], u32 *s_base, u32 *s_part)
+{
+	constexpr u32 RS_TILE = RS_THREADS * RS_ITEMS;
+	const u32 t = threadIdx.x, lane = t & 63u;
+	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+	const u32 base = tile * RS_TILE;
+	const u32 first = base + wave * (64u * RS_ITEMS); // (uniform: the loads take a scalar base and one lane offset)
+	u32 k[RS_ITEMS], v[RS_ITEMS], r[RS_ITEMS];
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++)
+		k[i] = FULL || first + (u32)i * 64u + lane < n ? kin[first + (u32)i * 64u + lane] : 0xFFFFFFFFu;
+	// (the values are requested with the keys: the ranks no longer need the registers they used to)
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++)
+		v[i] = FULL || first + (u32)i * 64u + lane < n ? vin[first + (u32)i * 64u + lane] : 0u;
+	d_rs_rank<RS_ITEMS, ATOMIC, FULL>(k, r, s_cnt[wave], shift, dmask, first, n, lane);
+	__syncthreads();
+	// digit d = thread d (the upper half of the block only takes part in the barriers): totals, offsets of
+	// the waves inside the digit, position of the digit in the tile
+	const bool digit = t < RS_BINS;
+	u32 total = 0, woff[RS_WAVES];
+	if (digit) {
+#pragma unroll
+		for (int w = 0; w < RS_WAVES; w++) {
+			woff[w] = total;
+			total += s_cnt[w][t];
+		}
+	}
+	const u32 lstart = d_block_excl_scan(total, s_part);
+	const u32 gdigit = d_block_excl_scan(digit ? hist[t] : 0u, s_part);
+	if (digit) {
+		// slot of a pair inside the sorted tile = s_cnt[its wave][its digit] + its rank
+#pragma unroll
+		for (int w = 0; w < RS_WAVES; w++)
+			s_cnt[w][t] = lstart + woff[w];
+		// digit t: offset of this tile = counts of all tiles before it, combined in two levels (no chain)
+		const u32 chunk = tile / RS_CHUNK, firstt = chunk * RS_CHUNK, nb = tile - firstt;
+		const u64w tag = (u64w)epoch << 32;
+		__hip_atomic_store(look + (size_t)tile * RS_BINS + t, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// the tiles before this one inside its chunk (they hold lower tickets: they run or have finished)
+		u32 excl = d_rs_wait_sum<(RS_ITEMS > 8 ? 8 : 4)>(look + (size_t)firstt * RS_BINS + t, nb, RS_BINS, epoch);
+		if (nb == RS_CHUNK - 1u) // the chunk is complete with this tile: publish its sum
+			__hip_atomic_store(look2 + (size_t)chunk * RS_BINS + t, tag | (u64w)(excl + total), __ATOMIC_RELAXED,
+					   __HIP_MEMORY_SCOPE_AGENT);
+		// the chunks before this one (their last tiles hold lower tickets)
+		excl += d_rs_wait_sum<(RS_ITEMS > 8 ? 8 : 4)>(look2 + t, chunk, RS_BINS, epoch);
+		s_base[t] = gdigit + excl - lstart; // global position of slot j of digit d = s_base[d] + j
+	}
+	__syncthreads();
+	// tile in digit order in LDS
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; i++) {
+		if (FULL || first + (u32)i * 64u + lane < n) {
+			const u32 d = (k[i] >> shift) & dmask;
+			const u32 slot = s_cnt[wave][d] + r[i];
+			s_keys[slot] = k[i];
+			s_vals[slot] = v[i];
+		}
+	}
+	__syncthreads();
+	const u32 ntile = FULL ? (u32)RS_TILE : n - base;
+#pragma unroll 4
+	for (u32 j = t; j < ntile; j += RS_THREADS) {
+		const u32 key = s_keys[j];
+		const u32 pos = s_base[(key >> shift) & dmask] + j;
+		kout[pos] = key;
+		vout[pos] = s_vals[j];
+	}
+}
+
 // look:  [tile][digit] tile counts;  look2: [chunk][digit] chunk sums;  ctl: {ticket, finished}
-template <int RS_ITEMS>
+template <int RS_ITEMS, bool ATOMIC>
 __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
 							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
 							 u32 dmask, u32 *hist, u64w *look, u64w *look2, u32 chunk_cap, u32 *ctl,
@@ -120,12 +239,11 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 		n = *n_dev < n ? *n_dev : n;
 	constexpr u32 RS_TILE = RS_THREADS * RS_ITEMS;
 	__shared__ u32 s_keys[RS_TILE], s_vals[RS_TILE];
-	__shared__ u32 s_cnt[RS_WAVES][RS_BINS]; // per wave: digit counters while ranking, then the wave's offset inside the digit
-	__shared__ u32 s_lstart[RS_BINS]; // first slot of the digit inside the sorted tile
-	__shared__ u32 s_base[RS_BINS];   // global position of slot j of digit d = s_base[d] + j
+	__shared__ u32 s_cnt[RS_WAVES][RS_BINS]; // per wave: digit counters while ranking, then the first slot of the wave's pairs of the digit
+	__shared__ u32 s_base[RS_BINS];
 	__shared__ u32 s_part[RS_WAVES];
 	__shared__ u32 s_tile, s_last;
-	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+	const u32 t = threadIdx.x;
 	if (t == 0)
 		s_tile = atomicAdd(&ctl[0], 1u);
 	for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS)
@@ -135,103 +253,13 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 	const u32 base = tile * RS_TILE;
 	// (a launch sized by the capacity: a tile beyond the pairs holds nothing, and no tile waits for a later one)
 	if (base < n) {
-	u32 k[RS_ITEMS], r[RS_ITEMS];
-#pragma unroll
-	for (int i = 0; i < RS_ITEMS; i++) {
-		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
-		k[i] = idx < n ? kin[idx] : 0xFFFFFFFFu;
+		if (n - base >= RS_TILE) // (no bounds checks in a full tile: all but the last)
+			d_rs_tile<RS_ITEMS, ATOMIC, true>(kin, vin, kout, vout, n, shift, dmask, hist, look, look2, epoch, tile, s_keys, s_vals,
+							  s_cnt, s_base, s_part);
+		else
+			d_rs_tile<RS_ITEMS, ATOMIC, false>(kin, vin, kout, vout, n, shift, dmask, hist, look, look2, epoch, tile, s_keys, s_vals,
+							   s_cnt, s_base, s_part);
 	}
-	// (small tiles have the registers to fetch the values beside the keys; large ones fetch them behind the look-back)
-	u32 v[RS_ITEMS];
-	if (RS_ITEMS <= 8) {
-#pragma unroll
-		for (int i = 0; i < RS_ITEMS; i++) {
-			const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
-			v[i] = idx < n ? vin[idx] : 0u;
-		}
-	}
-	// wave-synchronous ranking, items in memory order
-	volatile u32 *cnt = s_cnt[wave];
-	const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-	for (int i = 0; i < RS_ITEMS; i++) {
-		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
-		const bool ok = idx < n;
-		const u32 d = (k[i] >> shift) & dmask;
-		unsigned long long grp = __ballot(ok);
-#pragma unroll
-		for (int b = 0; b < 8; b++) {
-			const bool bit = (d >> b) & 1u;
-			const unsigned long long m = __ballot(bit);
-			grp &= bit ? m : ~m;
-		}
-		u32 old = 0;
-		if (ok)
-			old = cnt[d];
-		r[i] = old + (u32)__popcll(grp & lt);
-		__builtin_amdgcn_wave_barrier(); // every lane of the group has read the counter
-		if (ok && (grp & lt) == 0ull)
-			cnt[d] = old + (u32)__popcll(grp);
-		__builtin_amdgcn_wave_barrier();
-	}
-	__syncthreads();
-	// digit d = thread d (the upper half of the block only takes part in the barriers): totals, offsets of
-	// the waves inside the digit, position of the digit in the tile
-	const bool digit = t < RS_BINS;
-	u32 total = 0;
-	if (digit) {
-#pragma unroll
-		for (int w = 0; w < RS_WAVES; w++) {
-			const u32 c = s_cnt[w][t];
-			s_cnt[w][t] = total;
-			total += c;
-		}
-	}
-	const u32 lstart = d_block_excl_scan(total, s_part);
-	const u32 gdigit = d_block_excl_scan(digit ? hist[t] : 0u, s_part);
-	if (digit) {
-		// digit t: offset of this tile = counts of all tiles before it, combined in two levels (no chain)
-		const u32 chunk = tile / RS_CHUNK, first = chunk * RS_CHUNK, nb = tile - first;
-		const u64w tag = (u64w)epoch << 32;
-		__hip_atomic_store(look + (size_t)tile * RS_BINS + t, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		// the tiles before this one inside its chunk (they hold lower tickets: they run or have finished)
-		u32 excl = d_rs_wait_sum<(RS_ITEMS > 8 ? 8 : 4)>(look + (size_t)first * RS_BINS + t, nb, RS_BINS, epoch);
-		if (nb == RS_CHUNK - 1u) // the chunk is complete with this tile: publish its sum
-			__hip_atomic_store(look2 + (size_t)chunk * RS_BINS + t, tag | (u64w)(excl + total), __ATOMIC_RELAXED,
-					   __HIP_MEMORY_SCOPE_AGENT);
-		// the chunks before this one (their last tiles hold lower tickets)
-		excl += d_rs_wait_sum<(RS_ITEMS > 8 ? 8 : 4)>(look2 + t, chunk, RS_BINS, epoch);
-		s_lstart[t] = lstart;
-		s_base[t] = gdigit + excl - lstart;
-	} // digit
-	__syncthreads();
-	// tile in digit order in LDS (the values are fetched only now: they would occupy registers all the way)
-	if (RS_ITEMS > 8) {
-#pragma unroll
-		for (int i = 0; i < RS_ITEMS; i++) {
-			const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
-			v[i] = idx < n ? vin[idx] : 0u;
-		}
-	}
-#pragma unroll
-	for (int i = 0; i < RS_ITEMS; i++) {
-		const u32 idx = base + wave * (64u * RS_ITEMS) + (u32)i * 64u + lane;
-		if (idx < n) {
-			const u32 d = (k[i] >> shift) & dmask;
-			const u32 slot = s_lstart[d] + s_cnt[wave][d] + r[i];
-			s_keys[slot] = k[i];
-			s_vals[slot] = v[i];
-		}
-	}
-	__syncthreads();
-	const u32 ntile = (n - base) < (u32)RS_TILE ? (n - base) : (u32)RS_TILE;
-	for (u32 j = t; j < ntile; j += RS_THREADS) {
-		const u32 key = s_keys[j];
-		const u32 pos = s_base[(key >> shift) & dmask] + j;
-		kout[pos] = key;
-		vout[pos] = s_vals[j];
-	}
-	} // base < n
 	// the last workgroup to finish leaves this pass's histogram row, ticket and counter at zero for the next sort
 	// at this site (every workgroup has read its row by now: a workgroup counts itself in after its own reads)
 	__syncthreads();
@@ -248,6 +276,48 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 			ctl[1] = 0u;
 		}
 	}
+}
+
+// Does an LDS add-with-return serve the lanes of one instruction that hit the same word in lane order?  512 threads rank
+// 64 rounds of pseudo-random digits (1 to 256 distinct ones per round, so every conflict degree occurs) both ways;
+// bad[0] counts the ranks that differ.
+__global__ __launch_bounds__(RS_THREADS) void k_rs_selftest(u32 *bad)
+{
+	__shared__ u32 s_a[RS_WAVES][RS_BINS], s_b[RS_WAVES][RS_BINS];
+	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+	u32 wrong = 0;
+	for (u32 round = 0; round < 64u; round++) {
+		for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS) {
+			(&s_a[0][0])[i] = 0;
+			(&s_b[0][0])[i] = 0;
+		}
+		__syncthreads();
+		u32 k[16], ra[16], rb[16];
+		const u32 sel = round & 3u;
+		const u32 dmask = sel == 0u ? (2u << ((round >> 2) & 7u)) - 1u : 255u; // random digits: 2, 4, ... 256 distinct ones
+#pragma unroll
+		for (int i = 0; i < 16; i++) {
+			u32 x = (t * 16u + (u32)i) * 2654435761u + round * 40503u;
+			x ^= x >> 15;
+			x *= 2246822519u;
+			x ^= x >> 13;
+			k[i] = sel == 0u   ? x >> 7
+			       : sel == 1u ? lane / (1u + (round >> 2)) + (u32)i * 3u // runs of 1..16 neighbouring lanes
+			       : sel == 2u ? round                                    // every lane the same digit
+					   : (x >> 9) & 3u;                           // four digits
+		}
+		d_rs_rank<16, true, true>(k, ra, s_a[wave], 0u, dmask, 0u, 0u, lane);
+		d_rs_rank<16, false, true>(k, rb, s_b[wave], 0u, dmask, 0u, 0u, lane);
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+			wrong += ra[i] != rb[i] ? 1u : 0u;
+		__syncthreads();
+		for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS)
+			wrong += (&s_a[0][0])[i] != (&s_b[0][0])[i] ? 1u : 0u;
+		__syncthreads();
+	}
+	if (wrong)
+		atomicAdd(bad, wrong);
 }
 
 static int rs_state(ugrt_ctx *ctx, u32 tiles)
@@ -268,6 +338,16 @@ static int rs_state(ugrt_ctx *ctx, u32 tiles)
 		return rc;
 	}
 	UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, ctx->rs_state.cap, ctx->stream));
+	if (ctx->rs_atomic_rank < 0) {
+		// once per context: may the passes rank by LDS atomics on this device?  (the look-back words serve as scratch)
+		u32 *bad = (u32 *)ctx->rs_state.p + (size_t)RS_SITES * RS_SITE_WORDS, h_bad = 1;
+		hipLaunchKernelGGL(k_rs_selftest, dim3(4), dim3(RS_THREADS), 0, ctx->stream, bad);
+		UGRT_HIP(hipGetLastError());
+		UGRT_HIP(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+		UGRT_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
+		UGRT_HIP(hipStreamSynchronize(ctx->stream));
+		ctx->rs_atomic_rank = h_bad == 0u ? 1 : 0;
+	}
 	if (before) {
 		UGRT_HIP(hipMemcpyAsync(ctx->rs_state.p, before, (size_t)RS_SITES * RS_SITE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
 		UGRT_HIP(hipStreamSynchronize(ctx->stream));
@@ -347,7 +427,10 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 		hblocks = hblocks > 256u ? 256u : (hblocks ? hblocks : 1u);
 		hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, h, n_dev);
 		UGRT_HIP(hipGetLastError());
+		ctx->rs_launches++;
 	}
+	// ranks by LDS atomics where the device serves them in lane order (checked once per context), unless "sort_rank" is 0
+	const bool atomic_rank = ctx->rs_atomic_rank == 1 && ctx->opt[UGRT_OPT_SORT_RANK] != 0;
 	const u32 *ki = kin, *vi = vin;
 	for (int p = 0; p < passes; p++) {
 		// the buffers alternate so that the last pass writes the caller's output
@@ -358,14 +441,23 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 			UGRT_HIP(hipMemsetAsync(look, 0, ctx->rs_state.cap - (size_t)RS_SITES * RS_SITE_WORDS * 4, st));
 			ctx->rs_epoch = 1;
 		}
-		if (items == 8)
-			hipLaunchKernelGGL(k_rs_pass<8>, dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),
-					   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,
-					   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u);
-		else
-			hipLaunchKernelGGL(k_rs_pass<16>, dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),
-					   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,
-					   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u);
+#define RS_LAUNCH(ITEMS, ATOMIC)                                                                                                     \
+	hipLaunchKernelGGL((k_rs_pass<ITEMS, ATOMIC>), dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),     \
+			   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,       \
+			   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u)
+		if (items == 8) {
+			if (atomic_rank)
+				RS_LAUNCH(8, true);
+			else
+				RS_LAUNCH(8, false);
+		} else {
+			if (atomic_rank)
+				RS_LAUNCH(16, true);
+			else
+				RS_LAUNCH(16, false);
+		}
+#undef RS_LAUNCH
+		ctx->rs_launches++;
 		UGRT_HIP(hipGetLastError());
 		ki = ko;
 		vi = vo;

@@ -139,6 +139,12 @@ class Context:
         """Launch-shape options (no effect on results), e.g. "dda_rays_per_wave"."""
         check(lib.ugrt_ctx_set_option(self._h, key.encode(), int(value)))
 
+    def get_state(self, key):
+        """Counters and findings of the context: "radix_launches", "sort_rank_atomic"."""
+        v = C.c_longlong(0)
+        check(lib.ugrt_ctx_get_state(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def geometry_changed(self):
         """With FLAG_STATIC_GEOMETRY: the vertex or face array was rewritten outside ugrt_animate."""
         check(lib.ugrt_geometry_changed(self._h))

@@ -13,17 +13,26 @@
 // GPU): every rank renders its band with the same display(), and the RGB bands are gathered on rank 0 by RCCL
 // (ncclSend / ncclRecv inside one group: point-to-point fan-in, each peer on its own xGMI link) - the one
 // collective of a frame.  `ranks 1` runs the same gather on a communicator of one.
+// A rank that fails is an exit code, never a hang: every process runs a watchdog thread (started after the forks).
+// Rank 0's reaps the children as they end - a child that ends non-zero, or a rendezvous + ncclCommInitRank that
+// takes longer than `rendezvous_timeout` seconds (default 60), raises a shared flag, kills the other children and
+// exits 1 from under whatever call the main thread is blocked in; a child's leaves when the flag is up or its parent
+// is gone.  Every error exit of rank 0 (the *_CHECK macros call exit) raises the flag on its way out (atexit).
 //
 //   display_main PARAMS OUT.ppm        PARAMS: lines "key v0 v1 ..." (see read_params)
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 static int g_width = 1024, g_height = 1024; // main.cu.h:10-11
@@ -55,7 +64,7 @@ int frame_cnt = 0;
 struct Params {
 	char obj[512], mat[512];
 	float cam[11], light[11]; // eye, look, up, near, far
-	int streams, reflect, frames, animate_size, animate_offset, ranks;
+	int streams, reflect, frames, animate_size, animate_offset, ranks, rendezvous_timeout;
 	unsigned flags;
 } P;
 
@@ -67,7 +76,7 @@ static void read_params(const char *path)
 		exit(1);
 	}
 	char key[64];
-	P.streams = 1, P.frames = 1, P.ranks = 0;
+	P.streams = 1, P.frames = 1, P.ranks = 0, P.rendezvous_timeout = 60;
 	while (fscanf(fp, "%63s", key) == 1) {
 		if (!strcmp(key, "obj"))
 			(void)!fscanf(fp, "%511s", P.obj);
@@ -91,6 +100,8 @@ static void read_params(const char *path)
 			(void)!fscanf(fp, "%d", &P.frames);
 		else if (!strcmp(key, "ranks"))
 			(void)!fscanf(fp, "%d", &P.ranks);
+		else if (!strcmp(key, "rendezvous_timeout"))
+			(void)!fscanf(fp, "%d", &P.rendezvous_timeout);
 		else if (!strcmp(key, "flags"))
 			(void)!fscanf(fp, "%u", &P.flags);
 		else {
@@ -244,11 +255,84 @@ void display() // main.cu:59-302
 		}                                                                     \
 	} while (0)
 
-// what the ranks share before they have a communicator: rank 0's RCCL id
+// what the ranks share before (and beside) their communicator: rank 0's RCCL id, how far the start-up has come, and
+// whether any rank has failed
 struct Rendezvous {
 	ncclUniqueId id;
-	volatile int ready;
+	volatile int ready;  // the id is there
+	volatile int inited; // ranks whose ncclCommInitRank has returned
+	volatile int failed; // a rank ended badly, or the start-up took too long: everybody leaves
+	volatile int done;   // rank 0 has everything it needs from the others
 };
+static Rendezvous *g_rv;
+static std::vector<pid_t> g_children;
+static std::atomic<int> g_reaped{ 0 }, g_child_bad{ 0 };
+
+static double now_s()
+{
+	timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void kill_children()
+{
+	for (pid_t pid : g_children)
+		kill(pid, SIGKILL);
+	for (pid_t pid : g_children)
+		(void)waitpid(pid, nullptr, 0);
+}
+
+// rank 0 leaves through exit() on any error (the *_CHECK macros): the others must not wait for it
+static void parent_atexit()
+{
+	if (g_rv && !g_rv->done) {
+		g_rv->failed = 1;
+		kill_children();
+	}
+}
+
+// rank 0: reap the children as they end; a bad end or an overdue start-up ends the whole job with exit code 1
+static void parent_watchdog(int ranks, double deadline)
+{
+	for (;;) {
+		for (pid_t pid : g_children) {
+			int st = 0;
+			const pid_t r = waitpid(pid, &st, WNOHANG);
+			if (r == pid) {
+				g_reaped++;
+				if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+					fprintf(stderr, "display_main: rank process %d ended with status 0x%x\n", (int)pid, st);
+					g_child_bad = 1;
+				}
+			}
+		}
+		const bool late = g_rv->inited < ranks && now_s() > deadline;
+		if (late)
+			fprintf(stderr, "display_main: %d of %d ranks joined the communicator within the rendezvous timeout\n", g_rv->inited, ranks);
+		if ((g_child_bad && !g_rv->done) || late || g_rv->failed) {
+			g_rv->failed = 1;
+			for (pid_t pid : g_children)
+				kill(pid, SIGKILL);
+			for (pid_t pid : g_children)
+				(void)waitpid(pid, nullptr, 0);
+			_exit(1); // (from under whatever RCCL / HIP call the main thread is blocked in)
+		}
+		if (g_reaped == (int)g_children.size())
+			return;
+		usleep(20000);
+	}
+}
+
+// ranks > 0: leave when another rank has failed or rank 0 is gone
+static void child_watchdog(pid_t parent, double deadline, int ranks)
+{
+	for (;;) {
+		if (g_rv->failed || getppid() != parent || (g_rv->inited < ranks && now_s() > deadline))
+			_exit(1);
+		usleep(20000);
+	}
+}
 
 // tile rows [begin, end) of `rank`: sizes differ by at most one row (the rule of the Python harness: parallel.band_rows)
 static void band_rows(int rank, int ranks, int nby, int *begin, int *end)
@@ -269,26 +353,37 @@ int main(int argc, char **argv)
 	const int ranks = P.ranks > 0 ? P.ranks : 1;
 	int rank = 0;
 	Rendezvous *rv = nullptr;
-	std::vector<pid_t> children;
+	const pid_t parent = getpid();
 	if (P.ranks > 0) {
 		rv = (Rendezvous *)mmap(nullptr, sizeof(Rendezvous), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
 		if (rv == MAP_FAILED) {
 			perror("mmap");
 			return 1;
 		}
-		rv->ready = 0;
+		memset(rv, 0, sizeof(*rv));
+		g_rv = rv;
 		for (int r = 1; r < ranks; r++) {
 			const pid_t pid = fork();
 			if (pid < 0) {
 				perror("fork");
+				rv->failed = 1;
+				kill_children();
 				return 1;
 			}
 			if (pid == 0) {
 				rank = r;
-				children.clear();
+				g_children.clear();
 				break;
 			}
-			children.push_back(pid);
+			g_children.push_back(pid);
+		}
+		// (threads only now: the forks are behind us)
+		const double deadline = now_s() + (double)P.rendezvous_timeout;
+		if (rank == 0) {
+			atexit(parent_atexit);
+			std::thread(parent_watchdog, ranks, deadline).detach();
+		} else {
+			std::thread(child_watchdog, parent, deadline, ranks).detach();
 		}
 	}
 	int row_begin = 0, row_end = g_height / 8;
@@ -302,12 +397,13 @@ int main(int argc, char **argv)
 			__sync_synchronize();
 			rv->ready = 1;
 		} else {
-			while (!rv->ready)
+			while (!rv->ready) // (the watchdog ends this process if rank 0 fails or the deadline passes)
 				usleep(1000);
 			__sync_synchronize();
 		}
 		ncclUniqueId id = rv->id;
 		NCCL_CHECK(ncclCommInitRank(&comm, ranks, id, rank));
+		__sync_fetch_and_add(&rv->inited, 1);
 	}
 	if (P.ranks == 0) {
 		init_ugrt(g_width, g_height, P.flags);
@@ -387,15 +483,16 @@ int main(int argc, char **argv)
 		NCCL_CHECK(ncclCommDestroy(comm));
 	if (rank != 0)
 		return 0;
-	int bad = 0;
-	for (pid_t pid : children) {
-		int st = 0;
-		if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
-			bad = 1;
-	}
-	if (bad) {
-		fprintf(stderr, "a rank failed\n");
-		return 1;
+	// the children end by themselves now; the watchdog reaps them (and ends the job if one ends badly)
+	if (rv) {
+		const double until = now_s() + 60.0;
+		while (g_reaped < (int)g_children.size() && !g_child_bad && now_s() < until)
+			usleep(1000);
+		if (g_child_bad || g_reaped < (int)g_children.size()) {
+			fprintf(stderr, "a rank failed\n");
+			return 1; // (atexit: the flag goes up and what is left of the children is killed)
+		}
+		rv->done = 1;
 	}
 	writePPM(argv[2]);
 	printf("frames %d streams %d ranks %d chunks %zu\n", frame_cnt, P.streams, ranks, *dData->h_numCudaBlocks);

@@ -82,6 +82,72 @@ def test_cpp_display_writes_the_oracle_image(tmp_path, ugrt, O, streams, reflect
     assert want["image"].max() > 0 and want["is_shadowed"].sum() > 0
 
 
+def _group_is_empty(pgid):
+    try:
+        os.killpg(pgid, 0)
+    except ProcessLookupError:
+        return True
+    return False
+
+
+def _run_failing_ranks(tmp_path, ugrt, ranks, extra=""):
+    import signal
+    import time
+
+    _build()
+    d = str(tmp_path)
+    s = ugrt.scenes.hall(d, scale=0.05)
+    cam, lcam = s["cameras"]["ref"], s["light_camera"]
+    flat = lambda c: " ".join("%.9g" % v for v in (list(c["eye"]) + list(c["look"]) + list(c["up"]) + [c["near"], c["far"]]))
+    params = os.path.join(d, "params.txt")
+    with open(params, "w") as f:
+        f.write("obj %s\nmat %s\nsize 128 128\ncamera %s\nlight_camera %s\nshading_light 1 2 3\nranks %d\n%s"
+                % (s["obj"], s["mat"], flat(cam), flat(lcam), ranks, extra))
+    t0 = time.time()
+    p = subprocess.Popen([BIN, params, os.path.join(d, "out.ppm")], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, start_new_session=True)  # its own process group: nothing of it may be left behind
+    try:
+        out, err = p.communicate(timeout=60)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        p.communicate()
+        raise AssertionError("display_main with a failing rank hung (no exit within 60 s)")
+    took = time.time() - t0
+    for _ in range(100):  # (killed children are reaped by init a moment later)
+        if _group_is_empty(p.pid):
+            break
+        time.sleep(0.05)
+    left = not _group_is_empty(p.pid)
+    if left:
+        os.killpg(p.pid, signal.SIGKILL)
+    return p.returncode, took, left, out + err
+
+
+def test_cpp_display_rank_failure_is_an_exit_code_not_a_hang(tmp_path, ugrt):
+    """`ranks N` with one rank more than the box has GPUs (here, without a GPU: every rank): that rank's hipSetDevice
+    fails and it exits; rank 0 (blocked in ncclCommInitRank, or failing itself) must end the job with a non-zero exit
+    code within seconds and leave no process behind (watchdog threads + the shared failure flag)."""
+    import torch
+
+    ranks = torch.cuda.device_count() + 1  # (counting devices does not initialise the GPU)
+    rc, took, left, log = _run_failing_ranks(tmp_path, ugrt, max(2, ranks))
+    assert rc != 0, log
+    assert took < 30.0, "took %.1f s: %s" % (took, log)
+    assert not left, "processes of the job outlived it"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", ["", "rendezvous_timeout 2\n"])
+def test_cpp_display_failing_rank_on_the_gpu_box(tmp_path, ugrt, extra):
+    """The same on the GPU box (`ranks` = its GPUs + 1: the last rank cannot get a device while rank 0 waits in
+    ncclCommInitRank), with the default start-up deadline and with one of 2 s: whichever notices first (the reaped
+    child or the deadline), the job ends non-zero, at once, and leaves no process."""
+    import torch
+
+    rc, took, left, log = _run_failing_ranks(tmp_path, ugrt, torch.cuda.device_count() + 1, extra)
+    assert rc != 0 and took < 30.0 and not left, (rc, took, left, log)
+
+
 @pytest.mark.gpu
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: the parent starts the two ranks itself (it never touches

@@ -175,6 +175,85 @@ def cpu_baseline(ugrt, s, setup, W, H, lg, udims, seconds):
     return out
 
 
+def measure_config(ugrt, torch, s, W, H, local, reflect, animate, steps, warmup, frames_in_flight=4):
+    """One of BASELINE's other configurations, measured the way the headline is (two streams per renderer,
+    `frames_in_flight` renderers, builds that never wait, every frame complete) and verified the same way: the buffers
+    every renderer holds from its last frame against ONE sequential waiting-build context."""
+    device = torch.device("cuda", local)
+    setup = ugrt.FrameSetup.from_scene(s)
+    flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY
+    lg, udims = (128, 128), (128, 128, 64)
+    rs = []
+    for i in range(frames_in_flight):
+        stream = torch.cuda.Stream(device) if i else None
+        with torch.cuda.stream(stream):
+            cx = ugrt.Context(W, H, device=local, light_grid=lg, flags=flags, uniform_dims=udims)
+            rr = ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True,
+                               helper_thread=False)
+        rr._stream = stream
+        for c in [rr.ctx] + ([rr.aux] if rr.aux is not None else []):
+            c.set_option("async_build", 1)
+        if rr.aux is not None and frames_in_flight > 1:
+            rr.aux.set_option("dda_blocks", DDA_WAVES_THROUGHPUT)
+            rr.aux.set_option("dda_rays_per_wave", DDA_RPW_THROUGHPUT)
+            rr.aux.set_option("dda_split", DDA_SPLIT_THROUGHPUT)
+            rr.ctx.set_option("shadow_waves", SHADOW_WAVES_THROUGHPUT)
+        if animate:
+            rr.init_orig_list(s["animated_size"], s["animated_offset"])
+        rs.append(rr)
+    turn, frame_no = [0], [0]
+
+    def step():
+        rr = rs[turn[0] % len(rs)]
+        turn[0] += 1
+        with torch.cuda.stream(rr._stream):
+            if animate:
+                rr.rotate_bunny(1.81 + 0.05 * frame_no[0])
+                frame_no[0] += 1
+            rr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+
+    def drain():
+        for rr in rs:
+            rr.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 2 * len(rs))):
+        step()
+    drain()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    npix = rs[0].ctx.npix
+    active = [int(rr.active.sum().item()) if reflect else 0 for rr in rs]
+    rays = 2 * npix + sum(active) / float(len(active))
+    # verification: one sequential context (one stream, builds that wait), the geometry of every renderer's last frame
+    fctx = ugrt.Context(W, H, device=local, light_grid=lg, flags=flags, uniform_dims=udims)
+    fr = ugrt.Renderer(fctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"])
+    names = ["image", "is_shadowed", "intersect_id", "t", "normal", "dir"] + (["hit_t", "hit_id", "active"] if reflect else [])
+    bad = []
+    for rr in rs:
+        fr.d_verts.copy_(rr.d_verts)
+        fctx.geometry_changed()
+        fr.display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+        fctx.synchronize()
+        torch.cuda.synchronize()
+        bad.append([k for k in names if not torch.equal(getattr(fr, k).view(torch.uint8), getattr(rr, k).view(torch.uint8))])
+    verified = all(not b for b in bad)
+    out = {"ms_per_step": round(ms, 4), "frames_per_s": round(1e3 / ms, 2), "Mrays/s": round(rays / ms / 1e3, 1),
+           "rays_per_frame": int(rays), "triangles": int(s["num_faces"]), "size": [W, H], "steps": steps,
+           "frames_in_flight": len(rs), "verified": verified}
+    if not verified:
+        out["verify_mismatches_per_renderer"] = bad
+    for rr in rs:
+        rr.close()
+    del fr, fctx, rs
+    gc.collect()
+    torch.cuda.synchronize()
+    return out
+
+
 def launch_ranks(n):
     """`bench.py --gpus N` without an external launcher: start N ranks (one process per GPU) through
     torch.distributed.run and relay rank 0's JSON line.  This parent never touches the GPU and does not replace
@@ -248,6 +327,11 @@ def main():
                     help="cells of the bounce's uniform grid (A13 is this repo's own spec: any resolution gives the same hits)")
     ap.add_argument("--balance-rounds", type=int, default=4,
                     help="N > 1: rounds of timing the bands and moving their boundaries before the measurement (0 = equal bands)")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false", default=True,
+                    help="N = 1, default workload: skip the other BASELINE configurations behind the headline measurement "
+                         "(hall 1024x1024 primary + shadow = configs[1], the 3840x2160 frame on this one GPU = configs[3]'s "
+                         "per-GPU ceiling, the animated rebuild = configs[4]; ~10 verified steps each, reported under "
+                         "other_configs; the profile passes skip them so that their kernel averages are the headline's)")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
@@ -602,6 +686,8 @@ def main():
 
             verify_detail = []
             # N = 1: every renderer in flight holds the buffers of its last frame; N > 1: the gathered image
+            if os.environ.get("UGRT_BENCH_FORCE_MISMATCH") == "1":  # (tests: a frame that differs must fail the run)
+                last.image[0:3] = last.image[0:3] ^ 0xFF
             for rr in (renderers if world == 1 else [last]):
                 fr.d_verts.copy_(rr.d_verts)
                 fctx.geometry_changed()
@@ -627,9 +713,20 @@ def main():
     else:
         rays_total = float(rays_rank)
 
+    # a frame that differs from the sequential context's is not a result: every rank leaves with exit code 1 (rank 0
+    # after printing its line, with "value" null and an "error" field)
+    failed = False
+    if args.verify:
+        flag = torch.tensor([1.0 if (rank == 0 and verified is not True) else 0.0], dtype=torch.float64,
+                            device="cpu" if rehearse else ctx.device)
+        if dist is not None:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = bool(flag.item() > 0)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
+        if failed:
+            sys.exit(1)
         return
 
     stages = {k: dict(ms_per_launch=v[0] / v[1], launches_per_step=v[1] / float(nfull),
@@ -709,6 +806,35 @@ def main():
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement
             cpu = dict(value=None, unit="Mrays/s", cores=0, kind="port", sample="failed: %r" % (e,))
 
+    # the other BASELINE configurations, in this same process, behind the headline measurement (each verified)
+    other = None
+    default_run = (world == 1 and args.workload == "crash" and args.scale == 1.0 and not (args.width or args.height) and reflect
+                   and not args.animate and not args.no_overlap and shards is None and not args.waiting_builds and not args.opt)
+    if args.other_configs and default_run:
+        for rr in renderers:
+            rr.close()
+        gc.collect()
+        other = {}
+        t_other = time.time()
+        try:
+            hall = load_scene(ugrt, "hall", 1.0, rank)
+            other["hall_1024"] = dict(measure_config(ugrt, torch, hall, 1024, 1024, local, False, False, 10, 3),
+                                      config="BASELINE configs[1] stand-in: procedural hall, primary + shadow (1 light, all chunks)")
+            del hall
+            other["crash_4k"] = dict(measure_config(ugrt, torch, s, 3840, 2160, local, True, False, 10, 3),
+                                     config="BASELINE configs[3]'s frame (3840x2160, primary + shadow + bounce) on ONE GPU: "
+                                            "the per-GPU ceiling of the 8-GPU configuration")
+            other["animated"] = dict(measure_config(ugrt, torch, s, W, H, local, True, True, 10, 3),
+                                     config="BASELINE configs[4]: animated sub-range transformed and all three grids rebuilt "
+                                            "every frame, 1920x1080, primary + shadow + bounce")
+        except Exception as e:  # the headline stands; what failed is said
+            other["error"] = repr(e)
+        other["wall_s"] = round(time.time() - t_other, 1)
+        bad_other = [k for k, v in other.items() if isinstance(v, dict) and v.get("verified") is False]
+        if bad_other or "error" in other:
+            failed = True
+            verify_detail = (verify_detail or []) + [{"other_configs": bad_other or other.get("error")}]
+
     value = rays_total / elapsed * args.steps / 1e6
     line = {
         "metric": "Mrays/s (primary+shadow+1-bounce)",
@@ -767,13 +893,20 @@ def main():
         "band_bounds_tile_rows": list(bounds) if world > 1 else None,
         "band_balance_rounds": balance_log if world > 1 else None,
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},
+        "other_configs": other,
     }
+    if failed:
+        line["error"] = ("verification failed: the timed frames differ from the sequential waiting-build context in %r; "
+                         "the measured %.3f Mrays/s are withheld" % (verify_detail, value))
+        line["value"] = None
     if args.stages_json:
         with open(args.stages_json, "w") as fp:
             json.dump(dict(stages=stages, abytes=abytes, line=line), fp, indent=1)
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if failed:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -170,6 +170,28 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_fails_when_the_timed_frames_do_not_verify():
+    """bench.py compares what its timed renderers hold with one sequential context; a difference (forced here by
+    flipping one pixel before the comparison) must end the run with a non-zero exit code, `value` null and an `error`
+    field in the line - never a headline number with a false flag beside it."""
+    import json
+    import sys
+
+    env = dict(os.environ, UGRT_BENCH_FORCE_MISMATCH="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--repeats", "0",
+           "--scale", "0.05", "--width", "640", "--height", "360"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0, p.stdout[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["verified_against_single_context_frame"] is False and line["value"] is None and "error" in line
+    env.pop("UGRT_BENCH_FORCE_MISMATCH")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["verified_against_single_context_frame"] is True and line["value"] > 0 and "error" not in line
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--shard-builds"], ["--config3"]])
 def test_bench_two_ranks_on_one_gpu_gather_the_right_image(extra):
     """The N > 1 path of bench.py end to end with the real kernels: two ranks (both on this one GPU, gloo with host

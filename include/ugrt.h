@@ -199,8 +199,7 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64" shape the
  * shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix sort instead of the built-in
  * one, "sort_items" 8 / 16 pairs per thread of a radix pass (default: by size), "sort_rank" 0 = the passes rank by
- * ballots instead of LDS atomics, "sort_fused_hist" 1 = the kernels
- * that write sort keys count their digits (measured slower: DESIGN.md section 8); "dda_blocks", "primary_waves",
+ * ballots instead of LDS atomics; "dda_blocks", "primary_waves",
  * "shadow_waves": number of persistent single-wave workgroups of the bounce, the primary tracer and the two
  * shadow kernels (the primary tracer and the exact shadow pass run one wave per work item by default, "primary_xcd_run" /
  * "shadow_xcd_run" neighbouring items per XCD in turn; "primary_waves" set / "shadow_xcd_run" 0 restore their persistent

@@ -1322,22 +1322,21 @@ def test_async_builds_equal_the_waiting_form(ugrt, O, torch):
 
 
 @pytest.mark.parametrize("async_build", [0, 1])
-def test_fused_sort_histograms(ugrt, O, torch, async_build):
-    """Option "sort_fused_hist": the kernels that write sort keys (fill, shadow keys, pair compaction, item list) count
-    the keys' digits for the sort that follows instead of a histogram kernel reading them again; the sorts' state
-    cleans itself.  Same frame, several times in a row (the rows must be zero again after every sort)."""
+def test_sort_options_through_a_frame(ugrt, O, torch, async_build):
+    """The radix sort's forms under a whole frame (three grid builds, ray sort, the shadow tracer's three sorts): ranks by
+    LDS atomics / by ballots, tiles of 4096 / 8192 pairs, the library's sort.  Every pass counts the digit of the pass
+    that follows and the last workgroup of a pass clears its rows: the same frame several times in a row must keep
+    giving the oracle's grids and images (a row left dirty would misplace the next sort's digits)."""
     s = scene(ugrt, "crash")
     W, H, lg, ud = 256, 144, (64, 64), (32, 32, 16)
     setup = setup_for(ugrt, s, "ref")
     ctx, r = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
-    ctx.set_option("sort_fused_hist", 1)
     ctx.set_option("async_build", async_build)
     want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud, all_chunks=True)
-    for k in range(4):
-        if k == 2:
-            ctx.set_option("sort_fused_hist", 0)  # and back: both forms share the rows of a site
-        if k == 3:
-            ctx.set_option("sort_fused_hist", 1)
+    for k, (rank, items, library) in enumerate([(-1, -1, 0), (0, -1, 0), (-1, 8, 0), (0, 16, 0), (-1, 16, 0), (-1, -1, 1), (-1, -1, 0)]):
+        ctx.set_option("sort_rank", rank)
+        ctx.set_option("sort_items", items)
+        ctx.set_option("sort_library", library)
         r.display(setup, shadows=True, reflect=True)
         ctx.synchronize()
         for n, key in (("intersect_id", "mat_ids"), ("is_shadowed", "is_shadowed"), ("hit_id", "hit_id"), ("image", "image")):

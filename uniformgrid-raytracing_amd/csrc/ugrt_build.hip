@@ -376,37 +376,32 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restr
 	parts[b] = (u32)lo;
 }
 
-// (grid-stride over the workgroup-sized parts: a bounded number of workgroups, each of which also accumulates the
-// digit histograms of the sort that follows -- ugrt_rs_hist.h -- and adds them to the sort's rows once at its end)
+// (grid-stride over the workgroup-sized parts: a bounded number of workgroups)
 #define FILL_MAX_BLOCKS 8192u
 __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
 							 const u32 *__restrict__ parts, u32 R, int ny, int nz,
 							 u32 *__restrict__ keys, u32 *__restrict__ vals,
-							 u32 *__restrict__ zero, u32 nzero, const u32 *__restrict__ rw, RsHist hs)
+							 u32 *__restrict__ zero, u32 nzero, const u32 *__restrict__ rw)
 {
 	__shared__ u32 s_scan[FILL_LDS];
-	__shared__ u32 s_rsh[RS_MAXPASS * RS_BINS];
 	// the per-cell words the boundary kernels start from (run ends, run starts, cells_used) are cleared here
 	// instead of by a fill of their own
 	for (u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x; i < nzero; i += gridDim.x * BUILD_THREADS)
 		zero[i] = 0;
 	if (rw)
 		R = rw[0];
-	d_rs_hist_zero(s_rsh, hs);
 	const u32 nparts = (R + BUILD_THREADS - 1) / BUILD_THREADS;
 	for (u32 part = blockIdx.x; part < nparts; part += gridDim.x) {
 		const u32 r = part * BUILD_THREADS + threadIdx.x;
 		const int f_first = (int)parts[part], f_last = (int)parts[part + 1];
 		const int nrun = f_last - f_first + 1;
 		const bool in_lds = nrun <= FILL_LDS;
-		__syncthreads(); // the previous part's searches are done with s_scan (and the histogram block is zero)
+		__syncthreads(); // the previous part's searches are done with s_scan
 		if (in_lds)
 			for (int i = threadIdx.x; i < nrun; i += BUILD_THREADS)
 				s_scan[i] = scan[f_first + i];
 		__syncthreads();
-		const bool ok = r < R;
-		u32 key = 0;
-		if (ok) {
+		if (r < R) {
 			int lo = f_first, hi = f_last; // smallest f with scan[f] > r
 			if (in_lds) {
 				while (lo < hi) {
@@ -435,14 +430,10 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ 
 			u32 ij = local / sz;
 			u32 j = ij % sy;
 			u32 i = ij / sy;
-			key = ((x0 + i) * (u32)ny + (y0 + j)) * (u32)nz + (z0 + k);
-			keys[r] = key;
+			keys[r] = ((x0 + i) * (u32)ny + (y0 + j)) * (u32)nz + (z0 + k);
 			vals[r] = (u32)f;
 		}
-		d_rs_hist_add(s_rsh, hs, key, ok);
 	}
-	__syncthreads();
-	d_rs_hist_flush(s_rsh, hs);
 }
 
 // do_scan_dump + cudppCompact + create_histogram (misc_kernel.cu:4-60,
@@ -736,18 +727,14 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, chk);
-	// (the fill also accumulates the digit histograms of the sort of its keys)
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
-	RsHist hs = { nullptr, 0u, 0 };
-	if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gi, bits_for(C), &hs)))
-		return rc;
+	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1;
 	hipLaunchKernelGGL(k_fill, dim3(nparts < FILL_MAX_BLOCKS ? nparts : FILL_MAX_BLOCKS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, (const Rng *)G.rng.p, (const u32 *)G.parts.p, 0u, ny, nz, k0, v0, (u32 *)G.span.p,
-			   2u * C + 1u, (const u32 *)rw, hs);
+			   2u * C + 1u, (const u32 *)rw);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-	rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_GRID0 + gi, fused, k0, k1, v0, v1, launchRn, bits_for(C), rw)
+	rc = own_sort ? ugrt_sort_pairs_u32(ctx, k0, k1, v0, v1, launchRn, bits_for(C), rw)
 		      : ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, launchRn, bits_for(C), rw);
 	if (rc)
 		return rc;
@@ -864,17 +851,13 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p, BuildCheck{ nullptr, 0u, 0u, 0ull, 0ull, nullptr, nullptr, nullptr });
 		const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1 && Rn <= (1u << 30);
-		const bool fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
-		RsHist hs = { nullptr, 0u, 0 };
-		if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_GRID0 + gidx, bits_for(C), &hs)))
-			return rc;
 		hipLaunchKernelGGL(k_fill, dim3(nparts < FILL_MAX_BLOCKS ? nparts : FILL_MAX_BLOCKS), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0,
-				   (u32 *)G.span.p, 2u * C + 1u, (const u32 *)nullptr, hs);
+				   (u32 *)G.span.p, 2u * C + 1u, (const u32 *)nullptr);
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-		rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_GRID0 + gidx, fused, k0, k1, v0, v1, Rn, bits_for(C), nullptr)
+		rc = own_sort ? ugrt_sort_pairs_u32(ctx, k0, k1, v0, v1, Rn, bits_for(C), nullptr)
 			      : ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, Rn, bits_for(C));
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 		if (rc)

@@ -194,7 +194,7 @@ static const struct {
 	{ "shadow_xseg", 64, 1 << 20 }, { "shadow_sizebits", 0, 8 },    { "shadow_itemsort", 0, 1 },
 	{ "shadow_mbits", 1, 24 },      { "shadow_key64", 0, 1 },       { "sort_library", 0, 1 },
 	{ "async_build", 0, 1 },        { "primary_waves", 64, 1 << 20 },
-	{ "shadow_waves", 64, 1 << 20 }, { "dda_sort", 0, 1 }, { "sort_fused_hist", 0, 1 }, { "primary_order", 0, 1 }, { "primary_chunk", 4, 64 }, { "sort_items", 8, 16 }, { "dda_cull_work", 1, 1 << 30 },
+	{ "shadow_waves", 64, 1 << 20 }, { "dda_sort", 0, 1 }, { "primary_order", 0, 1 }, { "primary_chunk", 4, 64 }, { "sort_items", 8, 16 }, { "dda_cull_work", 1, 1 << 30 },
 	{ "dda_split", 0, 4 }, { "dda_split_load", 50, 100000 }, { "dda_split_segments", 1, 4 }, { "primary_xcd_run", 0, 4096 }, { "shadow_xcd_run", 0, 4096 },
 	{ "sort_rank", 0, 1 },
 };

@@ -37,7 +37,6 @@ enum {
 	UGRT_OPT_PRIMARY_WAVES,    // "primary_waves": single-wave workgroups of the primary tracer
 	UGRT_OPT_SHADOW_WAVES,     // "shadow_waves": the same for the two shadow kernels
 	UGRT_OPT_DDA_SORT,         // "dda_sort": 1 = the bounce's ray list is sorted by (entry cell, octant) instead of tile order
-	UGRT_OPT_SORT_FUSED,       // "sort_fused_hist": 1 = the kernels that write sort keys count their digits (default 0: a histogram kernel per sort; measured faster)
 	UGRT_OPT_PRIMARY_ORDER,    // "primary_order": 0 = a flush's jobs run in list order (default 1: nearest triangles first)
 	UGRT_OPT_PRIMARY_CHUNK,    // "primary_chunk": jobs between two looks at the rays' closest hits (4..64)
 	UGRT_OPT_SORT_ITEMS,       // "sort_items": pairs per thread of a radix pass, 16 (tiles of 8192) or 8 (4096)
@@ -130,11 +129,10 @@ struct ugrt_ctx {
 	DevBuf temp;                  // rocPRIM temporary storage
 	DevBuf scan_state;            // own scan: ticket + done counter (64 B), then one epoch-tagged state word per tile
 	u32 scan_epoch = 0;           // tag of the last scan's state words
-	DevBuf rs_state, rs_tmp[2];   // own radix sort: per-site histogram rows + tickets, look-back words; ping-pong buffers
+	DevBuf rs_state, rs_tmp[2];   // own radix sort: histogram rows + tickets, look-back words; ping-pong buffers
 	u32 rs_epoch = 0;             // tag of the last pass's look-back words
 	unsigned long long rs_launches = 0; // histogram + pass kernels enqueued so far (ugrt_ctx_get_state "radix_launches")
 	int rs_atomic_rank = -1;      // k_rs_selftest: 1 = LDS add-with-return serves equal addresses in lane order on this device
-	bool rs_dirty[8] = { false }; // per sort site: a producer was handed the histogram rows and its sort has not run yet
 	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
 	// gather ONE record per reference instead of 3 indices + 3 vertices
 	DevBuf trirec;

@@ -5,10 +5,13 @@
 // They are small (0.2-3 M pairs on 8-32 key bits), so the fixed cost per pass matters as much as the
 // bandwidth: a library onesweep spends one histogram kernel, one digit-scan kernel and 1 + 2*passes
 // buffer fills per sort besides the passes.  Here a sort is its passes and nothing else:
-//   - the digit histograms of all passes are accumulated by the kernel that writes the keys
-//     (ugrt_rs_hist.h; a histogram kernel remains for keys that come from outside);
+//   - a histogram kernel counts the FIRST pass's digit only; every pass counts the digit of the pass that follows
+//     while it holds the keys (LDS counters, one global add per digit and tile, spread over RS_COPIES rows).  Round 3
+//     counted all digits up front: 14-17 us per sort, as much as a pass (2-4 LDS atomics per key, mostly on one
+//     address per wave); counting in the kernels that WRITE the keys was tried too and lost to the global adds of their
+//     thousands of workgroups;
 //   - the state needs no clearing: the look-back words carry the EPOCH of their pass beside the count,
-//     and the last workgroup of a pass to finish zeroes that pass's histogram row, ticket and counter.
+//     and the last workgroup of a pass to finish zeroes that pass's histogram rows, ticket and counter.
 //
 // Pass kernel, one workgroup of 512 threads per tile of 8192 pairs:
 //   - tiles are taken in launch order from an atomic ticket, so a tile only ever waits for tiles that
@@ -31,21 +34,39 @@
 #define RS_ITEMS_MAX 16 // pairs per thread: 16 (tiles of 8192 pairs) or 8 (4096: option "sort_items")
 #define RS_CHUNK 16 // tiles per chunk of the two-level offset computation
 
-// state of one site (u32 words): histogram rows, then per pass {ticket, finished workgroups}
-#define RS_SITE_WORDS (RS_MAXPASS * RS_BINS + 2 * RS_MAXPASS + 56)
+// the sort's state (u32 words): histogram rows [pass][copy][digit], then per pass {ticket, finished workgroups}
+#define RS_HEAD_WORDS (RS_MAXPASS * RS_COPIES * RS_BINS + 2 * RS_MAXPASS + 56)
 
 typedef unsigned long long u64w; // look-back word: epoch << 32 | count
 
-// digit histograms of all passes in one read of the keys: for keys no kernel of this library wrote
-// (n_dev: the number of pairs when only the device knows it; n is then the capacity the launch was sized for)
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, RsHist h, const u32 *__restrict__ n_dev)
+// one more count of digit d in the workgroup's LDS histogram: one add per wave when all its keys share the digit
+// (neighbouring keys mostly do: cell ids in fill order, beams in candidate order), else one per lane
+__device__ __forceinline__ void d_rs_count(u32 *s_h, u32 d, bool ok)
+{
+	const unsigned long long act = __ballot(ok);
+	if (act == 0ull)
+		return;
+	const u32 first = (u32)__builtin_ctzll(act);
+	const u32 d0 = (u32)__builtin_amdgcn_readlane((int)d, (int)first);
+	if (__ballot(ok && d == d0) == act) {
+		if ((threadIdx.x & 63u) == first)
+			atomicAdd(&s_h[d0], (u32)__popcll(act));
+	} else if (ok) {
+		atomicAdd(&s_h[d], 1u);
+	}
+}
+
+// histogram of the first pass's digit (n_dev: the number of pairs when only the device knows it; n is then the
+// capacity the launch was sized for)
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, u32 dmask, u32 *hist, const u32 *__restrict__ n_dev)
 {
 	if (n_dev)
 		n = *n_dev < n ? *n_dev : n;
-	__shared__ u32 s_h[RS_MAXPASS * RS_BINS];
-	d_rs_hist_zero(s_h, h);
+	__shared__ u32 s_h[RS_BINS];
+	if (threadIdx.x < RS_BINS)
+		s_h[threadIdx.x] = 0u;
 	__syncthreads();
-	// few workgroups: every one ends with up to 256 * passes global adds on the same 256 * passes words
+	// few workgroups: every one ends with up to 256 global adds
 	const u32 stride = gridDim.x * RS_THREADS;
 	for (u32 i0 = blockIdx.x * RS_THREADS + threadIdx.x; i0 < n; i0 += 4u * stride) {
 		u32 k4[4];
@@ -54,10 +75,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
 			k4[u] = i0 + u * stride < n ? keys[i0 + u * stride] : 0u;
 #pragma unroll
 		for (u32 u = 0; u < 4; u++)
-			d_rs_hist_add(s_h, h, k4[u], i0 + u * stride < n);
+			d_rs_count(s_h, k4[u] & dmask, i0 + u * stride < n);
 	}
 	__syncthreads();
-	d_rs_hist_flush(s_h, h);
+	if (threadIdx.x < RS_BINS) {
+		const u32 c = s_h[threadIdx.x];
+		if (c)
+			atomicAdd(&hist[(blockIdx.x % RS_COPIES) * RS_BINS + threadIdx.x], c);
+	}
 }
 
 // exclusive scan of one value per thread over the threads of the block (s_part: RS_WAVES words of LDS)
@@ -127,9 +152,19 @@ __device__ __forceinline__ void d_rs_rank(const u32 (&k)[RS_ITEMS], u32 (&r)[RS_
 		const bool ok = FULL || first + (u32)i * 64u + lane < n;
 		const u32 d = (k[i] >> shift) & dmask;
 		if (ATOMIC) {
-			r[i] = 0;
-			if (ok)
-				r[i] = atomicAdd(&cnt[d], 1u);
+			// (a wave whose 64 keys share the digit -- sorted runs, constant upper digits -- would have its lanes served one
+			// after the other: there the rank is the lane and one lane adds 64)
+			const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)d);
+			if (FULL && __ballot(d == d0) == ~0ull) {
+				u32 old = 0;
+				if (lane == 0u)
+					old = atomicAdd(&cnt[d0], 64u);
+				r[i] = (u32)__builtin_amdgcn_readfirstlane((int)old) + lane;
+			} else {
+				r[i] = 0;
+				if (ok)
+					r[i] = atomicAdd(&cnt[d], 1u);
+			}
 		} else {
 			const unsigned long long act = FULL ? ~0ull : __ballot(ok);
 			u32 glo = (u32)act, ghi = (u32)(act >> 32);
@@ -157,8 +192,9 @@ __device__ __forceinline__ void d_rs_rank(const u32 (&k)[RS_ITEMS], u32 (&r)[RS_
 // the work of one tile that holds pairs: keys and values in, ranks, offsets (look-back), LDS reorder, scatter
 template <int RS_ITEMS, bool ATOMIC, bool FULL>
 __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
-					  u32 *__restrict__ vout, u32 n, u32 shift, u32 dmask, const u32 *hist, u64w *look, u64w *look2,
-					  u32 epoch, u32 tile, u32 *s_keys, u32 *s_vals, u32 (*s_cnt)[RS_BINS], u32 *s_base, u32 *s_part)
+					  u32 *__restrict__ vout, u32 n, u32 shift, u32 dmask, u32 gdigit_in, u32 *hist_next, u32 nmask,
+					  u64w *look, u64w *look2, u32 epoch, u32 tile, u32 *s_keys, u32 *s_vals, u32 (*s_cnt)[RS_BINS],
+					  u32 *s_base, u32 *s_part, u32 *s_next)
 {
 	constexpr u32 RS_TILE = RS_THREADS * RS_ITEMS;
 	const u32 t = threadIdx.x, lane = t & 63u;
@@ -174,6 +210,12 @@ __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32
 	for (int i = 0; i < RS_ITEMS; i++)
 		v[i] = FULL || first + (u32)i * 64u + lane < n ? vin[first + (u32)i * 64u + lane] : 0u;
 	d_rs_rank<RS_ITEMS, ATOMIC, FULL>(k, r, s_cnt[wave], shift, dmask, first, n, lane);
+	// the digit of the pass that follows, counted while the keys are here (nmask == 0: this is the last pass)
+	if (nmask) {
+#pragma unroll
+		for (int i = 0; i < RS_ITEMS; i++)
+			d_rs_count(s_next, (k[i] >> (shift + 8u)) & nmask, FULL || first + (u32)i * 64u + lane < n);
+	}
 	__syncthreads();
 	// digit d = thread d (the upper half of the block only takes part in the barriers): totals, offsets of
 	// the waves inside the digit, position of the digit in the tile
@@ -186,8 +228,13 @@ __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32
 			total += s_cnt[w][t];
 		}
 	}
+	if (nmask && digit) { // (the adds are on their way while the tile goes on)
+		const u32 c = s_next[t];
+		if (c)
+			atomicAdd(&hist_next[(tile % RS_COPIES) * RS_BINS + t], c);
+	}
 	const u32 lstart = d_block_excl_scan(total, s_part);
-	const u32 gdigit = d_block_excl_scan(digit ? hist[t] : 0u, s_part);
+	const u32 gdigit = d_block_excl_scan(gdigit_in, s_part);
 	if (digit) {
 		// slot of a pair inside the sorted tile = s_cnt[its wave][its digit] + its rank
 #pragma unroll
@@ -228,12 +275,15 @@ __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32
 	}
 }
 
-// look:  [tile][digit] tile counts;  look2: [chunk][digit] chunk sums;  ctl: {ticket, finished}
+// hist: this pass's rows [copy][digit] (complete: the kernel before wrote them);  hist_next: the rows of the pass that
+// follows (nmask = its digit mask, 0 on the last pass);  look: [tile][digit] tile counts;  look2: [chunk][digit] chunk
+// sums;  ctl: {ticket, finished}
 template <int RS_ITEMS, bool ATOMIC>
 __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
 							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
-							 u32 dmask, u32 *hist, u64w *look, u64w *look2, u32 chunk_cap, u32 *ctl,
-							 u32 epoch, const u32 *__restrict__ n_dev, u32 rows_to_clear)
+							 u32 dmask, u32 *hist, u32 *hist_next, u32 nmask, u64w *look, u64w *look2,
+							 u32 chunk_cap, u32 *ctl, u32 epoch, const u32 *__restrict__ n_dev,
+							 u32 rows_to_clear)
 {
 	if (n_dev)
 		n = *n_dev < n ? *n_dev : n;
@@ -241,11 +291,20 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 	__shared__ u32 s_keys[RS_TILE], s_vals[RS_TILE];
 	__shared__ u32 s_cnt[RS_WAVES][RS_BINS]; // per wave: digit counters while ranking, then the first slot of the wave's pairs of the digit
 	__shared__ u32 s_base[RS_BINS];
+	__shared__ u32 s_next[RS_BINS]; // the following pass's digit, counted here
 	__shared__ u32 s_part[RS_WAVES];
 	__shared__ u32 s_tile, s_last;
 	const u32 t = threadIdx.x;
 	if (t == 0)
 		s_tile = atomicAdd(&ctl[0], 1u);
+	// this pass's digit totals are asked for before anything else (they are needed behind the ranks)
+	u32 gdigit_in = 0;
+	if (t < RS_BINS) {
+#pragma unroll
+		for (int c = 0; c < RS_COPIES; c++)
+			gdigit_in += hist[c * RS_BINS + t];
+		s_next[t] = 0u;
+	}
 	for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS)
 		(&s_cnt[0][0])[i] = 0;
 	__syncthreads();
@@ -254,22 +313,20 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 	// (a launch sized by the capacity: a tile beyond the pairs holds nothing, and no tile waits for a later one)
 	if (base < n) {
 		if (n - base >= RS_TILE) // (no bounds checks in a full tile: all but the last)
-			d_rs_tile<RS_ITEMS, ATOMIC, true>(kin, vin, kout, vout, n, shift, dmask, hist, look, look2, epoch, tile, s_keys, s_vals,
-							  s_cnt, s_base, s_part);
+			d_rs_tile<RS_ITEMS, ATOMIC, true>(kin, vin, kout, vout, n, shift, dmask, gdigit_in, hist_next, nmask, look, look2, epoch,
+							  tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
 		else
-			d_rs_tile<RS_ITEMS, ATOMIC, false>(kin, vin, kout, vout, n, shift, dmask, hist, look, look2, epoch, tile, s_keys, s_vals,
-							   s_cnt, s_base, s_part);
+			d_rs_tile<RS_ITEMS, ATOMIC, false>(kin, vin, kout, vout, n, shift, dmask, gdigit_in, hist_next, nmask, look, look2, epoch,
+							   tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
 	}
-	// the last workgroup to finish leaves this pass's histogram row, ticket and counter at zero for the next sort
-	// at this site (every workgroup has read its row by now: a workgroup counts itself in after its own reads)
+	// the last workgroup to finish leaves this pass's histogram rows, ticket and counter at zero for the next sort
+	// (every workgroup has read the rows by now: a workgroup counts itself in after its own reads)
 	__syncthreads();
 	if (t == 0)
 		s_last = atomicAdd(&ctl[1], 1u) == gridDim.x - 1u ? 1u : 0u;
 	__syncthreads();
 	if (s_last) {
-		// (the last pass also clears the rows above its own: a producer that did not know the key width has counted
-		// zeros into them)
-		for (u32 i = t; i < rows_to_clear * RS_BINS; i += RS_THREADS)
+		for (u32 i = t; i < rows_to_clear * RS_COPIES * RS_BINS; i += RS_THREADS)
 			hist[i] = 0u;
 		if (t == 0) {
 			ctl[0] = 0u;
@@ -322,14 +379,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_selftest(u32 *bad)
 
 static int rs_state(ugrt_ctx *ctx, u32 tiles)
 {
-	// [RS_SITES] site blocks, then the look-back words of the running pass: tile counts, chunk sums
+	// the head (histogram rows, tickets), then the look-back words of the running pass: tile counts, chunk sums
 	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
 	const size_t look_words64 = (size_t)chunks * RS_CHUNK * RS_BINS + (size_t)chunks * RS_BINS;
-	const size_t bytes = (size_t)RS_SITES * RS_SITE_WORDS * 4 + look_words64 * 8;
-	const void *before = ctx->rs_state.p;
+	const size_t bytes = (size_t)RS_HEAD_WORDS * 4 + look_words64 * 8;
 	if (bytes <= ctx->rs_state.cap)
 		return UGRT_OK;
-	// growing: the site blocks of a sort in preparation (histogram rows a producer has added to) must survive
+	// growing: between two sorts the head is all zeros (every pass cleans up behind itself), so nothing is carried over
 	DevBuf old = ctx->rs_state;
 	ctx->rs_state = DevBuf();
 	int rc = ugrt_buf_reserve(ctx, ctx->rs_state, bytes);
@@ -340,7 +396,7 @@ static int rs_state(ugrt_ctx *ctx, u32 tiles)
 	UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, ctx->rs_state.cap, ctx->stream));
 	if (ctx->rs_atomic_rank < 0) {
 		// once per context: may the passes rank by LDS atomics on this device?  (the look-back words serve as scratch)
-		u32 *bad = (u32 *)ctx->rs_state.p + (size_t)RS_SITES * RS_SITE_WORDS, h_bad = 1;
+		u32 *bad = (u32 *)ctx->rs_state.p + RS_HEAD_WORDS, h_bad = 1;
 		hipLaunchKernelGGL(k_rs_selftest, dim3(4), dim3(RS_THREADS), 0, ctx->stream, bad);
 		UGRT_HIP(hipGetLastError());
 		UGRT_HIP(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -348,48 +404,20 @@ static int rs_state(ugrt_ctx *ctx, u32 tiles)
 		UGRT_HIP(hipStreamSynchronize(ctx->stream));
 		ctx->rs_atomic_rank = h_bad == 0u ? 1 : 0;
 	}
-	if (before) {
-		UGRT_HIP(hipMemcpyAsync(ctx->rs_state.p, before, (size_t)RS_SITES * RS_SITE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
-		UGRT_HIP(hipStreamSynchronize(ctx->stream));
+	if (old.p) {
+		UGRT_HIP(hipStreamSynchronize(ctx->stream)); // (a pass of the previous sort may still read the old words)
 		(void)hipFree(old.p);
 	}
 	ctx->rs_epoch = 0;
 	return UGRT_OK;
 }
 
-int ugrt_sort_hist_arg(ugrt_ctx *ctx, int site, int end_bit, RsHist *out)
+// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
+// (n_dev != nullptr: the pair count lives on the device and n is the capacity the launches are sized for)
+int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
+			const u32 *n_dev)
 {
-	int rc = rs_state(ctx, 1);
-	if (rc)
-		return rc;
-	if (end_bit < 1)
-		end_bit = 1;
-	if (end_bit > 32)
-		end_bit = 32;
-	static_assert(RS_SITES <= 8, "ugrt_ctx::rs_dirty");
-	if (ctx->rs_dirty[site] && (rc = ugrt_sort_hist_reset(ctx, site))) // a producer ran and its sort never did (an error between them)
-		return rc;
-	ctx->rs_dirty[site] = true;
-	out->hist = (u32 *)ctx->rs_state.p + (size_t)site * RS_SITE_WORDS;
-	out->end_bit = (u32)end_bit;
-	out->passes = (end_bit + 7) / 8;
-	return UGRT_OK;
-}
-
-// forget what a producer has added to a site's rows (its sort will not run: the producer is repeated)
-int ugrt_sort_hist_reset(ugrt_ctx *ctx, int site)
-{
-	if (!ctx->rs_state.p)
-		return UGRT_OK;
-	UGRT_HIP(hipMemsetAsync((u32 *)ctx->rs_state.p + (size_t)site * RS_SITE_WORDS, 0, (size_t)RS_MAXPASS * RS_BINS * 4, ctx->stream));
-	ctx->rs_dirty[site] = false;
-	return UGRT_OK;
-}
-
-int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n,
-			 int end_bit, const u32 *n_dev)
-{
-	if (n == 0 && !prehist)
+	if (n == 0)
 		return UGRT_OK;
 	if (n > ((size_t)1 << 30))
 		return ugrt_fail(UGRT_EINVAL, "sort: %zu pairs exceed 2^30", n);
@@ -398,34 +426,28 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 	if (end_bit > 32)
 		end_bit = 32;
 	const int passes = (end_bit + 7) / 8;
-	// pairs per thread: tiles of 4096 pairs finish a pass of up to ~1 M pairs in 15-23 us (8192: 18-25), tiles of 8192
-	// are faster from 2 M on (30 against 35 us, 44 against 65 at 4 M: half the tickets and look-back rows)
+	// pairs per thread: tiles of 4096 pairs finish a pass of up to ~1 M pairs sooner, tiles of 8192 are faster from 1 M
+	// on (half the tickets and look-back rows; profiles/r04_sort_bench_*.json)
 	const int items = ctx->opt[UGRT_OPT_SORT_ITEMS] > 0 ? (ctx->opt[UGRT_OPT_SORT_ITEMS] == 8 ? 8 : 16) : (n <= (3u << 18) ? 8 : 16);
 	const u32 RS_TILE = (u32)(RS_THREADS * items);
-	const u32 tiles = n ? (u32)((n + RS_TILE - 1) / RS_TILE) : 1u; // (n == 0 with histogram rows to clear: one idle tile)
+	const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
 	hipStream_t st = ctx->stream;
 	int rc;
 	if ((rc = rs_state(ctx, tiles)))
 		return rc;
 	if (passes > 1) {
-		if ((rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[0], (n ? n : 1) * 4)) || (rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[1], (n ? n : 1) * 4)))
+		if ((rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[0], n * 4)) || (rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[1], n * 4)))
 			return rc;
 	}
-	if (prehist)
-		ctx->rs_dirty[site] = false;
-	u32 *sitep = (u32 *)ctx->rs_state.p + (size_t)site * RS_SITE_WORDS;
-	u32 *hist = sitep, *ctl = sitep + RS_MAXPASS * RS_BINS;
+	u32 *hist = (u32 *)ctx->rs_state.p, *ctl = hist + RS_MAXPASS * RS_COPIES * RS_BINS;
 	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
-	u64w *look = (u64w *)((u32 *)ctx->rs_state.p + (size_t)RS_SITES * RS_SITE_WORDS);
+	u64w *look = (u64w *)((u32 *)ctx->rs_state.p + RS_HEAD_WORDS);
 	u64w *look2 = look + (size_t)chunks * RS_CHUNK * RS_BINS;
-	if (!prehist) {
-		RsHist h;
-		h.hist = hist;
-		h.end_bit = (u32)end_bit;
-		h.passes = passes;
+	auto bits_of_pass = [end_bit](int p) { return (u32)(end_bit - 8 * p) < 8u ? (u32)(end_bit - 8 * p) : 8u; };
+	{
 		u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
 		hblocks = hblocks > 256u ? 256u : (hblocks ? hblocks : 1u);
-		hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, h, n_dev);
+		hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, (1u << bits_of_pass(0)) - 1u, hist, n_dev);
 		UGRT_HIP(hipGetLastError());
 		ctx->rs_launches++;
 	}
@@ -436,15 +458,15 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 		// the buffers alternate so that the last pass writes the caller's output
 		const bool to_out = ((passes - 1 - p) & 1) == 0;
 		u32 *ko = to_out ? kout : (u32 *)ctx->rs_tmp[0].p, *vo = to_out ? vout : (u32 *)ctx->rs_tmp[1].p;
-		const u32 bits = (u32)(end_bit - 8 * p) < 8u ? (u32)(end_bit - 8 * p) : 8u;
+		const u32 bits = bits_of_pass(p), nmask = p + 1 < passes ? (1u << bits_of_pass(p + 1)) - 1u : 0u;
 		if (++ctx->rs_epoch == 0u) { // (2^32 passes later: old tags could be taken for new ones)
-			UGRT_HIP(hipMemsetAsync(look, 0, ctx->rs_state.cap - (size_t)RS_SITES * RS_SITE_WORDS * 4, st));
+			UGRT_HIP(hipMemsetAsync(look, 0, ctx->rs_state.cap - (size_t)RS_HEAD_WORDS * 4, st));
 			ctx->rs_epoch = 1;
 		}
 #define RS_LAUNCH(ITEMS, ATOMIC)                                                                                                     \
 	hipLaunchKernelGGL((k_rs_pass<ITEMS, ATOMIC>), dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),     \
-			   (1u << bits) - 1u, hist + (size_t)p * RS_BINS, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev,       \
-			   p == passes - 1 ? (u32)(RS_MAXPASS - p) : 1u)
+			   (1u << bits) - 1u, hist + (size_t)p * RS_COPIES * RS_BINS, hist + (size_t)(p + 1 < passes ? p + 1 : p) * RS_COPIES * RS_BINS, \
+			   nmask, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev, 1u)
 		if (items == 8) {
 			if (atomic_rank)
 				RS_LAUNCH(8, true);
@@ -463,11 +485,4 @@ int ugrt_sort_pairs_site(ugrt_ctx *ctx, int site, bool prehist, const u32 *kin, 
 		vi = vo;
 	}
 	return UGRT_OK;
-}
-
-// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
-int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
-			const u32 *n_dev)
-{
-	return ugrt_sort_pairs_site(ctx, RS_SITE_MISC, false, kin, kout, vin, vout, n, end_bit, n_dev);
 }

@@ -832,20 +832,14 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 							     const u32 *__restrict__ span, const float *__restrict__ cmPt,
 							     u32 mbits, void *__restrict__ keys, u32 *__restrict__ vals,
 							     u32 *__restrict__ zero, u32 nzero,
-							     const u32 *__restrict__ nchunks_dev, u32 launch_cap, u32 prefix_cap, RsHist hs)
+							     const u32 *__restrict__ nchunks_dev, u32 launch_cap, u32 prefix_cap)
 {
-	// (grid-stride: a bounded number of workgroups, which also accumulate the digit histograms of the sort of these
-	// keys -- ugrt_rs_hist.h; 64-bit keys go to the library's sort and are not counted)
-	__shared__ u32 s_rsh[RS_MAXPASS * RS_BINS];
+	// (grid-stride: a bounded number of workgroups)
 	for (u32 z = blockIdx.x * WL_THREADS + threadIdx.x; z < nzero; z += gridDim.x * WL_THREADS)
 		zero[z] = 0; // run starts/ends per light cell, written after the sort
-	d_rs_hist_zero(s_rsh, hs);
-	__syncthreads();
 	for (u32 i0 = blockIdx.x * WL_THREADS; i0 < n; i0 += gridDim.x * WL_THREADS) {
 	const u32 i = i0 + threadIdx.x;
-	const bool ok = i < n;
-	u32 key32 = 0;
-	if (ok) {
+	if (i < n) {
 	if (nchunks_dev) { // the chunk count never went to the host (UGRT_CHUNKS_ON_DEVICE): same rule, here
 		nchunks = *nchunks_dev;
 		// more chunks than the caller's prefix map holds: the host path refuses that (ugrt_sort_rays_chunks
@@ -875,14 +869,10 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 	if (KEY64)
 		((u64 *)keys)[i] = ((u64)cell << 30) | (u64)code;
 	else
-		((u32 *)keys)[i] = key32 = (cell << mbits) | code;
+		((u32 *)keys)[i] = (cell << mbits) | code;
 	vals[i] = pixel;
-	} // ok
-	if (!KEY64)
-		d_rs_hist_add(s_rsh, hs, key32, ok);
+	} // i < n
 	} // grid-stride
-	__syncthreads();
-	d_rs_hist_flush(s_rsh, hs);
 }
 
 template <typename K>
@@ -1089,14 +1079,12 @@ __device__ __forceinline__ void d_flush_pairs(const u32 *buf_beam, const u32 *bu
 __global__ __launch_bounds__(256) void k_pair_compact(const u32 *__restrict__ segcnt, u32 segcap,
 						       const u32 *__restrict__ sbeam, const u32 *__restrict__ stri,
 						       u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri,
-						       u32 *__restrict__ pair_count, RsHist hs)
+						       u32 *__restrict__ pair_count)
 {
 	__shared__ u32 s_cnt[PAIR_SEGS], s_base[PAIR_SEGS];
 	__shared__ u32 s_over;
-	__shared__ u32 s_rsh[RS_MAXPASS * RS_BINS]; // digit histograms of the pair sort that follows (ugrt_rs_hist.h)
 	if (threadIdx.x == 0)
 		s_over = 0u;
-	d_rs_hist_zero(s_rsh, hs);
 	__syncthreads();
 	if (threadIdx.x < PAIR_SEGS) {
 		const u32 c = segcnt[threadIdx.x * PAIR_SEG_STRIDE];
@@ -1122,17 +1110,11 @@ __global__ __launch_bounds__(256) void k_pair_compact(const u32 *__restrict__ se
 	const size_t src = (size_t)seg * segcap;
 	for (u32 i0 = part * 256u; i0 < n; i0 += parts * 256u) {
 		const u32 i = i0 + threadIdx.x;
-		const bool ok = i < n;
-		u32 key = 0;
-		if (ok) {
-			key = sbeam[src + i];
-			pair_beam[base + i] = key;
+		if (i < n) {
+			pair_beam[base + i] = sbeam[src + i];
 			pair_tri[base + i] = stri[src + i];
 		}
-		d_rs_hist_add(s_rsh, hs, key, ok);
 	}
-	__syncthreads();
-	d_rs_hist_flush(s_rsh, hs);
 }
 
 // A cull item = (light cell, batch of 64 of its triangles, chunk of GCHUNK of its beams), as the kernel needs it:
@@ -1400,12 +1382,8 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_items(const u32 *__restrict
 							    const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
 							    const GBox *__restrict__ boxes, u32 XSEG,
 							    u32 *__restrict__ item_seg, u32 *__restrict__ item_sub,
-							    u32 *__restrict__ status, RsHist hs)
+							    u32 *__restrict__ status)
 {
-	// (grid-stride; the workgroups also count the items' 8-bit keys for the sort that follows -- ugrt_rs_hist.h)
-	__shared__ u32 s_rsh[RS_MAXPASS * RS_BINS];
-	d_rs_hist_zero(s_rsh, hs);
-	__syncthreads();
 	const u32 nitems = xincl[G - 1];
 	if (status && blockIdx.x == 0 && threadIdx.x == 0 && nitems > cap)
 		atomicOr(status, UGRT_STATUS_ITEM_OVERFLOW); // asynchronous form: the list was sized by an estimate
@@ -1426,10 +1404,7 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_items(const u32 *__restrict
 			item_seg[it] = seg;
 			item_sub[it] = sub;
 		}
-		d_rs_hist_add(s_rsh, hs, seg, ok);
 	}
-	__syncthreads();
-	d_rs_hist_flush(s_rsh, hs);
 }
 
 // EXACT pass: item -> (beam, segment of its candidate list, 64-ray sub-group); lane = ray, the reference's test
@@ -1659,27 +1634,21 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if (ctx->opt[UGRT_OPT_SHADOW_MBITS] > 0 && (u32)ctx->opt[UGRT_OPT_SHADOW_MBITS] < mbits)
 		mbits = (u32)ctx->opt[UGRT_OPT_SHADOW_MBITS];
 	mbits = mbits > 24u ? 24u : mbits;
-	// the kernels that write sort keys also count their digits (ugrt_rs_hist.h), unless the library's sort is asked for
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1, fused = own_sort && ctx->opt[UGRT_OPT_SORT_FUSED] == 1;
-	const RsHist hs_none = { nullptr, 0u, 0 };
+	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1;
 	const u32 kblocks = (u32)((n + WL_THREADS - 1) / WL_THREADS) < 768u ? (u32)((n + WL_THREADS - 1) / WL_THREADS) : 768u;
 	if (key64) {
 		hipLaunchKernelGGL(k_shadow_keys<true>, dim3(kblocks), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity, hs_none);
+				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity);
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs64(ctx, (const u64 *)k0, (u64 *)k1, v0, v1, n, 30 + (int)cellbits)))
 			return rc;
 	} else {
-		RsHist hs = hs_none;
-		if (fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_RAYS, (int)(mbits + cellbits), &hs)))
-			return rc;
 		hipLaunchKernelGGL(k_shadow_keys<false>, dim3(kblocks), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity, hs);
+				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity);
 		UGRT_HIP(hipGetLastError());
-		if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_RAYS, fused, (const u32 *)k0, (u32 *)k1, v0, v1, n,
-							  (int)(mbits + cellbits), nullptr)
+		if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits), nullptr)
 				   : ugrt_prim_sort_pairs(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits))))
 			return rc;
 	}
@@ -1773,16 +1742,9 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 					   (const u32 *)gincl, C, d_span, d_offset, d_value_list, rec, d_vertlist, d_trilist,
 					   (const GBox *)boxes, segcnt, segcap, (u32 *)ctx->tkey[1].p, (u32 *)ctx->tval[1].p, sbits,
 					   (const CullItem *)ctx->citem.p);
-		RsHist hsp = hs_none; // (the width of the pair keys depends on the beam count, which the waiting form learns later)
-		if (fused) {
-			if (attempt > 0 && (rc = ugrt_sort_hist_reset(ctx, RS_SITE_SHADOW_PAIRS))) // the first attempt's counts
-				return rc;
-			if ((rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_PAIRS, 32, &hsp)))
-				return rc;
-		}
 		hipLaunchKernelGGL(k_pair_compact, dim3(PAIR_SEGS * 16u), dim3(256), 0, st, (const u32 *)segcnt, segcap,
 				   (const u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[1].p, (u32 *)ctx->tkey[0].p,
-				   (u32 *)ctx->tval[0].p, pcount, hsp);
+				   (u32 *)ctx->tval[0].p, pcount);
 		ugrt_prof_end(ctx, UGRT_ST_SHADOW_CULL);
 		UGRT_HIP(hipGetLastError());
 		if (async) {
@@ -1829,13 +1791,13 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		ctx->h_pinned[UGRT_PIN_SHADOW + 1] = G;
 		ctx->shadow_async_pending = false;
 		if (P == 0 || G == 0)
-			return fused ? ugrt_sort_hist_reset(ctx, RS_SITE_SHADOW_PAIRS) : UGRT_OK; // (no pairs: nothing was counted)
+			return UGRT_OK;
 		xcap = (G + P / XSEG) * (beam / 64u); // >= number of exact-pass items
 	}
 	// 3. candidates by beam
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
-	if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_PAIRS, fused, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p,
-						  (const u32 *)ctx->tval[0].p, (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)
+	if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
+						 (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)
 			   : ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
 						  (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)))
 		return rc;
@@ -1855,18 +1817,15 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	u32 *iseg0 = (u32 *)ctx->sitem.p, *isub0 = iseg0 + xcap, *iseg1 = isub0 + xcap, *isub1 = iseg1 + xcap;
 	const bool item_sort = ctx->opt[UGRT_OPT_SHADOW_ITEMSORT] != 0;
-	RsHist hsi = hs_none;
-	if (item_sort && fused && (rc = ugrt_sort_hist_arg(ctx, RS_SITE_SHADOW_ITEMS, 8, &hsi)))
-		return rc;
 	{
 		const u32 ib = (xcap + WL_THREADS - 1) / WL_THREADS;
 		hipLaunchKernelGGL(k_pair_items, dim3(ib < 512u ? (ib ? ib : 1u) : 512u), dim3(WL_THREADS), 0, st,
 				   (const u32 *)xincl, Gcap, xcap, (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, XSEG,
-				   iseg0, isub0, async ? status : (u32 *)nullptr, hsi);
+				   iseg0, isub0, async ? status : (u32 *)nullptr);
 	}
 	UGRT_HIP(hipGetLastError());
 	if (item_sort) {
-		if ((rc = own_sort ? ugrt_sort_pairs_site(ctx, RS_SITE_SHADOW_ITEMS, fused, iseg0, iseg1, isub0, isub1, xcap, 8, nullptr)
+		if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, iseg0, iseg1, isub0, isub1, xcap, 8, nullptr)
 				   : ugrt_prim_sort_pairs(ctx, iseg0, iseg1, isub0, isub1, xcap, 8)))
 			return rc;
 	} else {

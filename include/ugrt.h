@@ -61,7 +61,15 @@ enum {
 	 * (the reference's other writer is the per-frame upload of scene.h:70 frames).  The builds then
 	 * keep the per-triangle records of the previous build instead of rewriting them three times a
 	 * frame.  Without the flag every build assumes new geometry, as the reference does. */
-	UGRT_FLAG_STATIC_GEOMETRY = 4u
+	UGRT_FLAG_STATIC_GEOMETRY = 4u,
+	/* ray set-up (trace_kernel.cu:96-105, per_frame_funcs.h:421-433): the reference samples its 5x5 direction
+	 * texture through the texture unit's linear filter, whose interpolation weights have 8 fractional bits.  By default
+	 * the fetch is the exact float bilinear interpolation at texel coordinate 4 ftx, which has the
+	 * same weights k/256 at width and height 1024 and finer ones elsewhere.  With this flag the weights are quantised
+	 * as the CUDA programming guide states the rule (ugrt_tex_linear8 in ugrt_fmath.h: coordinate ftx*0.8+0.1 on 5
+	 * texels, alpha rounded to 8 fractional bits): identical rays at 1024 x 1024, other rays at 1920 or 3840.  What the
+	 * reference's GPU really does beyond the documented rule cannot be checked here: parity unpinned either way. */
+	UGRT_FLAG_STRICT_TEXTURE = 8u
 };
 
 /* which grid of the context */

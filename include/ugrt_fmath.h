@@ -64,6 +64,32 @@ UGRT_HD float ugrt_floorf(float x)
 	return t;
 }
 
+/*
+ * UGRT_FLAG_STRICT_TEXTURE: position and weight of CUDA's linear texture filter for the normalized coordinate x on N
+ * texels, as the CUDA C Programming Guide states it ("Texture Fetching", linear filtering): xB = N x - 0.5,
+ * i = floor(xB), alpha = frac(xB) "stored in 9-bit fixed point format with 8 bits of fractional value".  The guide
+ * does not say how alpha is rounded (nearest is taken here) nor how the unit forms xB, and no CUDA device is here
+ * to ask: PARITY UNPINNED.  Clamp addressing: the last texel pair is used with alpha = 1 at the upper edge.
+ */
+UGRT_HD void ugrt_tex_linear8(float x, int N, int *i_out, float *alpha_out)
+{
+	float xB = x * (float)N - 0.5f, fl, q;
+	int i;
+	if (!(xB > 0.0f))
+		xB = 0.0f;
+	fl = ugrt_floorf(xB);
+	i = ugrt_f2i(fl);
+	if (i > N - 2) {
+		i = N - 2;
+		fl = (float)i;
+	}
+	q = ugrt_floorf((xB - fl) * 256.0f + 0.5f);
+	if (q > 256.0f)
+		q = 256.0f;
+	*i_out = i;
+	*alpha_out = q * (1.0f / 256.0f);
+}
+
 /* (int)floor(x) */
 UGRT_HD int ugrt_floor2i(float x)
 {

@@ -687,6 +687,13 @@ static float orc_intersect_tri_uv(const float *tvec, const float *edge1, const f
  * interpolation below (texel coordinate 4*ftx; at W = 1024 the weights are the
  * same k/256 values the hardware filter uses).  See DESIGN.md "ray set-up".
  */
+static int g_strict_texture = 0;
+/* UGRT_FLAG_STRICT_TEXTURE for every ray set-up that follows (test infrastructure: a process-wide switch) */
+void orc_set_strict_texture(int on)
+{
+	g_strict_texture = on != 0;
+}
+
 void orc_ray_dir(const float *cc, const float *tex, int col, int row, int W, int H, float *ray_direction)
 {
 	float ftx = (float)col / (float)W;
@@ -704,6 +711,10 @@ void orc_ray_dir(const float *cc, const float *tex, int col, int row, int W, int
 		j = 3;
 	a = xs - (float)i;
 	b = ys - (float)j;
+	if (g_strict_texture) {
+		ugrt_tex_linear8(ftx * 0.8f + 0.1f, 5, &i, &a);
+		ugrt_tex_linear8(fty * 0.8f + 0.1f, 5, &j, &b);
+	}
 	w00 = (1.0f - a) * (1.0f - b);
 	w10 = a * (1.0f - b);
 	w01 = (1.0f - a) * b;

@@ -293,11 +293,18 @@ def shade_reflect(cc, light_pos, img, normal, t, dirs, ids, cam_pos, mat_idx, ma
                            _p(rays), _p(active), _p(hit_t), _p(hit_id), C.c_int(p0), C.c_int(n))
 
 
+def set_strict_texture(on):
+    """UGRT_FLAG_STRICT_TEXTURE for the ray set-ups that follow (a process-wide switch of the checker)."""
+    _lib.orc_set_strict_texture(C.c_int(1 if on else 0))
+
+
 def frame(scene, setup, W, H, rows=None, light_grid=(128, 128), all_chunks=False, shadows=True, reflect=False,
-          uniform_dims=(64, 64, 32), frame_cnt=1, reflect_eps=1e-3, verts=None, slabs=1):
+          uniform_dims=(64, 64, 32), frame_cnt=1, reflect_eps=1e-3, verts=None, slabs=1, strict_texture=False):
     """display(), main.cu:59-302, on the CPU.  Returns every intermediate array and, in
     r["times"], the seconds spent per stage (used by bench.py's cpu_baseline leg)."""
     import time as _time
+
+    set_strict_texture(strict_texture)
 
     times = {}
 

@@ -413,6 +413,80 @@ def test_bounce_split_walks_on_a_moving_scene(ugrt, torch, rpw):
         assert went_on > 0 and cut_frames >= 2, (went_on, cut_frames)
 
 
+def test_bounce_split_history_survives_toggles(ugrt, O, torch):
+    """The split walks' per-pixel history is neither cleared nor refreshed while the option is off, and it is laid out
+    for one rays-per-wave setting: dda_split 1 -> 0 -> 1 with a moved camera in between, and dda_rays_per_wave changed
+    between launches (32 -> 64 -> 16 -> 32) -- every frame against the oracle's bounce, bit for bit."""
+    s = scene(ugrt, "crash")
+    W, H, lg, ud = 384, 216, (64, 64), (32, 32, 16)
+    cams = [setup_for(ugrt, s, "ref")]
+    moved = dict(s["cameras"]["ref"])
+    moved["eye"] = tuple(np.asarray(moved["eye"], np.float32) + np.float32([0.6, 0.25, -0.4]))
+    cams.append(ugrt.FrameSetup(moved, s["light_camera"], s["shading_light"]))
+    want = [O.frame(s, c, W, H, light_grid=lg, reflect=True, uniform_dims=ud, all_chunks=True) for c in cams]
+    ctx, r = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    ctx.set_option("dda_split_load", 50)  # cut every group above half the average: the path is exercised
+    # (split, rays per wave, camera)
+    plan = [(1, 32, 0), (1, 32, 0), (0, 32, 1), (1, 32, 1), (1, 32, 0), (1, 64, 0), (1, 64, 1), (0, 16, 1), (1, 16, 0),
+            (1, 32, 0), (2, 32, 1), (1, 64, 1)]
+    cut = 0
+    for k, (split, rpw, cam) in enumerate(plan):
+        ctx.set_option("dda_split", split)
+        ctx.set_option("dda_rays_per_wave", rpw)
+        r.display(cams[cam], shadows=True, reflect=True)
+        ctx.synchronize()
+        what = "launch %d: split %d, %d rays per wave, camera %d" % (k, split, rpw, cam)
+        np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want[cam]["hit_id"], err_msg=what)
+        assert_bits_equal(r.hit_t.cpu().numpy(), want[cam]["hit_t"], "bounce t, " + what)
+        np.testing.assert_array_equal(r.image.cpu().numpy(), want[cam]["image"], err_msg=what)
+        cut += 1 if (split and ctx.stats_dda_split()["segments"]) else 0
+    assert cut >= 3, cut
+
+
+LAUNCH_SHAPES = [("primary_waves", 64), ("primary_waves", 4096), ("primary_xcd_run", 0), ("primary_xcd_run", 1),
+                 ("primary_xcd_run", 7), ("primary_xcd_run", 4096), ("shadow_xcd_run", 0), ("shadow_xcd_run", 1),
+                 ("shadow_xcd_run", 4096), ("shadow_waves", 64), ("primary_order", 0), ("primary_chunk", 4),
+                 ("primary_chunk", 64), ("primary_seg", 64), ("shadow_beam", 64), ("shadow_beam", 8192), ("shadow_xseg", 64),
+                 ("shadow_sizebits", 0), ("shadow_itemsort", 0), ("shadow_mbits", 9)]
+
+
+@pytest.mark.parametrize("name,W,H", [("crash", 384, 216), ("hall", 256, 256)])
+def test_launch_shape_options_do_not_change_a_result(ugrt, O, torch, name, W, H):
+    """include/ugrt.h says no launch-shape option changes a result.  Every one that selects another code path of the
+    primary tracer or the shadow pass (persistent waves with XCD slices, XCD runs of any length, the persistent exact
+    pass, list-order flushes, the padding-entry skip behind the item capacity) runs here, alone and all at once, waiting
+    and asynchronous builds: ids, t, shadow flags and the image equal the oracle's."""
+    s = scene(ugrt, name)
+    lg, ud = (64, 64), (32, 32, 16)
+    setup = setup_for(ugrt, s, "ref")
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=False, all_chunks=True)
+
+    def check(r, what):
+        np.testing.assert_array_equal(r.intersect_id.cpu().numpy(), want["mat_ids"], err_msg=what)
+        assert_bits_equal(r.t.cpu().numpy(), want["primary"]["t"], "t, " + what)
+        assert_bits_equal(r.normal.cpu().numpy(), want["primary"]["normal"].reshape(-1), "normal, " + what)
+        np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"], err_msg=what)
+        np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"], err_msg=what)
+
+    ctx, r = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, udims=ud)
+    for async_build in (0, 1):
+        ctx.set_option("async_build", async_build)
+        for key, value in LAUNCH_SHAPES:
+            ctx.set_option(key, value)
+            for _ in range(2 if async_build else 1):  # (the second asynchronous frame runs on the first one's estimates)
+                r.display(setup, shadows=True)
+                ctx.synchronize()
+                check(r, "%s=%d async_build=%d" % (key, value, async_build))
+            ctx.set_option(key, -1)
+    # several at once
+    for key, value in (("primary_waves", 192), ("shadow_xcd_run", 0), ("shadow_waves", 128), ("primary_order", 0),
+                       ("primary_chunk", 8), ("shadow_beam", 128)):
+        ctx.set_option(key, value)
+    r.display(setup, shadows=True)
+    ctx.synchronize()
+    check(r, "combined")
+
+
 def test_band_split_equals_full_frame(ugrt, O, torch):
     """Image-tile sharding (multi-GPU path): two contexts with complementary tile-row bands
     produce exactly the full frame's primary outputs and the oracle's band results."""
@@ -1319,6 +1393,34 @@ def test_async_builds_equal_the_waiting_form(ugrt, O, torch):
     r4.display(setup_for(ugrt, big, "ref"), shadows=True, reflect=True)
     ctx3.synchronize()
     np.testing.assert_array_equal(r3.image.cpu().numpy(), r4.image.cpu().numpy())
+
+
+@pytest.mark.parametrize("W,H", [(1024, 1024), (640, 360)])
+def test_strict_texture_flag(ugrt, O, torch, W, H):
+    """UGRT_FLAG_STRICT_TEXTURE (parity unpinned): kernel and oracle share ugrt_tex_linear8, so the frame equals the
+    oracle's strict frame bit for bit; at 1024 x 1024 it also equals the default frame, at 640 x 360 it does not."""
+    s = scene(ugrt, "hall")
+    setup = setup_for(ugrt, s, "ref")
+    lg = (64, 64)
+    rows = (H // 16 - 4, H // 16 + 4)
+    ctx, r = make(ugrt, s, W, H, lg, rows=rows, flags=ugrt.FLAG_STRICT_TEXTURE)
+    r.display(setup, shadows=True)
+    ctx.synchronize()
+    ctx0, r0 = make(ugrt, s, W, H, lg, rows=rows)
+    r0.display(setup, shadows=True)
+    ctx0.synchronize()
+    try:
+        want = O.frame(s, setup, W, H, rows=rows, light_grid=lg, strict_texture=True)
+    finally:
+        O.set_strict_texture(False)
+    sl = slice(ctx.p0, ctx.p0 + ctx.npix)
+    sl3 = slice(3 * ctx.p0, 3 * (ctx.p0 + ctx.npix))
+    assert_bits_equal(r.dir.cpu().numpy()[sl3], want["primary"]["dir"].reshape(-1)[sl3], "dir")
+    assert_bits_equal(r.t.cpu().numpy()[sl], want["primary"]["t"][sl], "t")
+    np.testing.assert_array_equal(r.is_shadowed.cpu().numpy()[sl], want["is_shadowed"][sl])
+    np.testing.assert_array_equal(r.image.cpu().numpy()[sl3], want["image"].reshape(-1)[sl3])
+    same = bool(torch.equal(r.dir[sl3].view(torch.int32), r0.dir[sl3].view(torch.int32)))
+    assert same == (W == 1024)
 
 
 @pytest.mark.parametrize("async_build", [0, 1])

@@ -147,3 +147,22 @@ def test_slabs_one_equals_the_unslabbed_path(O, ugrt):
     # it never finds MORE hits than the single-slab walk, and the scene keeps some
     hit4, hit1 = b["primary"]["id"] >= 0, a["primary"]["id"] >= 0
     assert hit4.sum() > 0 and not (hit4 & ~hit1).any()
+
+
+def test_strict_texture_weights(O, ugrt):
+    """UGRT_FLAG_STRICT_TEXTURE (parity unpinned: CUDA's documented 8-bit weight rule, ugrt_fmath.h ugrt_tex_linear8):
+    at 1024 x 1024 the exact float weights ARE multiples of 1/256, so the rays are bit-identical to the default path;
+    at 1920 x 1080 they are not, and the quantised weights give other rays."""
+    s = ugrt.scenes.cornell()
+    setup = ugrt.FrameSetup(s["cameras"]["B"], s["light_camera"], s["shading_light"])
+    try:
+        for W, H, same in ((1024, 1024, True), (1920, 1080, False)):
+            rows = (H // 16 - 2, H // 16 + 2)
+            a = O.frame(s, setup, W, H, rows=rows, shadows=False)["primary"]
+            b = O.frame(s, setup, W, H, rows=rows, shadows=False, strict_texture=True)["primary"]
+            equal = np.array_equal(a["dir"].view(np.uint32), b["dir"].view(np.uint32))
+            assert equal == same, (W, H)
+            if not same:  # still the same picture to within the filter's resolution
+                assert np.abs(a["dir"] - b["dir"]).max() < 2e-3 and (a["id"] == b["id"]).mean() > 0.98
+    finally:
+        O.set_strict_texture(False)

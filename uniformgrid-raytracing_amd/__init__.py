@@ -50,6 +50,7 @@ UGRT_OK, UGRT_EINVAL, UGRT_ENODEV, UGRT_EHIP, UGRT_EIO, UGRT_ENOMEM, UGRT_EOVERF
 FLAG_SHADOW_ALL_CHUNKS = 1
 FLAG_COUNT_WORK = 2
 FLAG_STATIC_GEOMETRY = 4
+FLAG_STRICT_TEXTURE = 8
 CHUNKS_ON_DEVICE = 0xFFFFFFFF
 GRID_PERSPECTIVE, GRID_SPHERICAL, GRID_UNIFORM = 0, 1, 2
 STAGES = [

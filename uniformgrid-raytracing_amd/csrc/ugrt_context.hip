@@ -87,6 +87,7 @@ extern "C" int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cf
 	ctx->cam.H = cfg->height;
 	ctx->cam.nbx = nbx;
 	ctx->cam.nby = nby;
+	ctx->cam.strict_tex = (cfg->flags & UGRT_FLAG_STRICT_TEXTURE) ? 1 : 0;
 	hipError_t e = hipHostMalloc((void **)&ctx->h_pinned, UGRT_PIN_WORDS * sizeof(u32), hipHostMallocDefault);
 	if (e == hipSuccess)
 		memset(ctx->h_pinned, 0, UGRT_PIN_WORDS * sizeof(u32));

@@ -16,6 +16,7 @@ struct CamBlock {
 	float cc[64];   // dd_camcoords
 	float light[4]; // dd_light_position[0..2]
 	int W, H, nbx, nby;
+	int strict_tex; // UGRT_FLAG_STRICT_TEXTURE: the direction fetch with the texture unit's 8-bit weights
 };
 
 // launch-shape options (ugrt_ctx_set_option): none changes a result

@@ -137,6 +137,10 @@ __device__ __forceinline__ void d_ray_dir(const CamBlock &cam, const float *__re
 	i = i > 3 ? 3 : i;
 	j = j > 3 ? 3 : j;
 	float a = xs - (float)i, b = ys - (float)j;
+	if (cam.strict_tex) { // (uniform: a scalar branch) the reference's own coordinates through the documented filter rule
+		ugrt_tex_linear8(ftx * 0.8f + 0.1f, 5, &i, &a);
+		ugrt_tex_linear8(fty * 0.8f + 0.1f, 5, &j, &b);
+	}
 	float w00 = (1.0f - a) * (1.0f - b);
 	float w10 = a * (1.0f - b);
 	float w01 = (1.0f - a) * b;

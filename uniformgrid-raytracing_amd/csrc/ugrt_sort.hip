@@ -39,21 +39,27 @@
 
 typedef unsigned long long u64w; // look-back word: epoch << 32 | count
 
-// one more count of digit d in the workgroup's LDS histogram: one add per wave when all its keys share the digit
-// (neighbouring keys mostly do: cell ids in fill order, beams in candidate order), else one per lane
+// one more count of digit d in the workgroup's LDS histogram.  Neighbouring keys mostly share their digit (cell ids in
+// fill order, beams in candidate order), and lanes that add to one word are served one after the other: the wave's
+// largest groups are added by one lane each (up to four, as long as they are large), the rest lane by lane.
 __device__ __forceinline__ void d_rs_count(u32 *s_h, u32 d, bool ok)
 {
-	const unsigned long long act = __ballot(ok);
-	if (act == 0ull)
-		return;
-	const u32 first = (u32)__builtin_ctzll(act);
-	const u32 d0 = (u32)__builtin_amdgcn_readlane((int)d, (int)first);
-	if (__ballot(ok && d == d0) == act) {
-		if ((threadIdx.x & 63u) == first)
-			atomicAdd(&s_h[d0], (u32)__popcll(act));
-	} else if (ok) {
-		atomicAdd(&s_h[d], 1u);
+	unsigned long long rem = __ballot(ok);
+	const u32 lane = threadIdx.x & 63u;
+#pragma unroll 1
+	for (int it = 0; it < 4 && rem; it++) {
+		const u32 first = (u32)__builtin_ctzll(rem);
+		const u32 d0 = (u32)__builtin_amdgcn_readlane((int)d, (int)first);
+		const unsigned long long m = __ballot(ok && d == d0) & rem;
+		const u32 c = (u32)__popcll(m);
+		if (lane == first)
+			atomicAdd(&s_h[d0], c);
+		rem &= ~m;
+		if (c < 12u) // (many small groups: their lanes hardly meet)
+			break;
 	}
+	if ((rem >> lane) & 1ull)
+		atomicAdd(&s_h[d], 1u);
 }
 
 // histogram of the first pass's digit (n_dev: the number of pairs when only the device knows it; n is then the

@@ -39,27 +39,24 @@
 
 typedef unsigned long long u64w; // look-back word: epoch << 32 | count
 
-// one more count of digit d in the workgroup's LDS histogram.  Neighbouring keys mostly share their digit (cell ids in
-// fill order, beams in candidate order), and lanes that add to one word are served one after the other: the wave's
-// largest groups are added by one lane each (up to four, as long as they are large), the rest lane by lane.
+// One more count of digit d in the workgroup's LDS histogram.  Neighbouring keys mostly share their digit (cell ids in
+// fill order, beams in candidate order), and lanes that add to one word -- or to one bank -- are served one after the
+// other.  The histogram is therefore kept RS_PRIV-fold, lane l adds to copy l % RS_PRIV, and the copies of a digit lie
+// next to each other (in different banks): 64 equal digits are four adds deep instead of 64.  (Sorting out the wave's
+// groups first -- one add per group by a leader lane -- was measured too: the scalar loop cost more than the adds.)
+#define RS_PRIV 16
 __device__ __forceinline__ void d_rs_count(u32 *s_h, u32 d, bool ok)
 {
-	unsigned long long rem = __ballot(ok);
-	const u32 lane = threadIdx.x & 63u;
-#pragma unroll 1
-	for (int it = 0; it < 4 && rem; it++) {
-		const u32 first = (u32)__builtin_ctzll(rem);
-		const u32 d0 = (u32)__builtin_amdgcn_readlane((int)d, (int)first);
-		const unsigned long long m = __ballot(ok && d == d0) & rem;
-		const u32 c = (u32)__popcll(m);
-		if (lane == first)
-			atomicAdd(&s_h[d0], c);
-		rem &= ~m;
-		if (c < 12u) // (many small groups: their lanes hardly meet)
-			break;
-	}
-	if ((rem >> lane) & 1ull)
-		atomicAdd(&s_h[d], 1u);
+	if (ok)
+		atomicAdd(&s_h[d * RS_PRIV + (threadIdx.x & (RS_PRIV - 1u))], 1u);
+}
+__device__ __forceinline__ u32 d_rs_count_sum(const u32 *s_h, u32 d)
+{
+	u32 c = 0;
+#pragma unroll
+	for (u32 k = 0; k < RS_PRIV; k++)
+		c += s_h[d * RS_PRIV + ((k + d) & (RS_PRIV - 1u))]; // (rotated: the digit threads of a wave start in different banks)
+	return c;
 }
 
 // histogram of the first pass's digit (n_dev: the number of pairs when only the device knows it; n is then the
@@ -68,9 +65,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
 {
 	if (n_dev)
 		n = *n_dev < n ? *n_dev : n;
-	__shared__ u32 s_h[RS_BINS];
-	if (threadIdx.x < RS_BINS)
-		s_h[threadIdx.x] = 0u;
+	__shared__ u32 s_h[RS_BINS * RS_PRIV];
+	for (u32 i = threadIdx.x; i < RS_BINS * RS_PRIV; i += RS_THREADS)
+		s_h[i] = 0u;
 	__syncthreads();
 	// few workgroups: every one ends with up to 256 global adds
 	const u32 stride = gridDim.x * RS_THREADS;
@@ -85,7 +82,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ 
 	}
 	__syncthreads();
 	if (threadIdx.x < RS_BINS) {
-		const u32 c = s_h[threadIdx.x];
+		const u32 c = d_rs_count_sum(s_h, threadIdx.x);
 		if (c)
 			atomicAdd(&hist[(blockIdx.x % RS_COPIES) * RS_BINS + threadIdx.x], c);
 	}
@@ -235,11 +232,11 @@ __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32
 		}
 	}
 	if (nmask && digit) { // (the adds are on their way while the tile goes on)
-		const u32 c = s_next[t];
+		const u32 c = d_rs_count_sum(s_next, t);
 		if (c)
 			atomicAdd(&hist_next[(tile % RS_COPIES) * RS_BINS + t], c);
 	}
-	const u32 lstart = d_block_excl_scan(total, s_part);
+	const u32 lstart = d_block_excl_scan(total, s_part); // (its barriers also stand between the reads of s_next above and the reorder below)
 	const u32 gdigit = d_block_excl_scan(gdigit_in, s_part);
 	if (digit) {
 		// slot of a pair inside the sorted tile = s_cnt[its wave][its digit] + its rank
@@ -297,7 +294,8 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 	__shared__ u32 s_keys[RS_TILE], s_vals[RS_TILE];
 	__shared__ u32 s_cnt[RS_WAVES][RS_BINS]; // per wave: digit counters while ranking, then the first slot of the wave's pairs of the digit
 	__shared__ u32 s_base[RS_BINS];
-	__shared__ u32 s_next[RS_BINS]; // the following pass's digit, counted here
+	u32 *s_next = s_keys; // the following pass's digit is counted in the tile's key space, which is free until the reorder (RS_PRIV copies)
+	static_assert(RS_BINS * RS_PRIV <= RS_THREADS * 8, "the privatised histogram must fit the smallest tile's keys");
 	__shared__ u32 s_part[RS_WAVES];
 	__shared__ u32 s_tile, s_last;
 	const u32 t = threadIdx.x;
@@ -309,8 +307,10 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 #pragma unroll
 		for (int c = 0; c < RS_COPIES; c++)
 			gdigit_in += hist[c * RS_BINS + t];
-		s_next[t] = 0u;
 	}
+	if (nmask)
+		for (u32 i = t; i < RS_BINS * RS_PRIV; i += RS_THREADS)
+			s_next[i] = 0u;
 	for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS)
 		(&s_cnt[0][0])[i] = 0;
 	__syncthreads();

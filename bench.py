@@ -581,6 +581,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    radix0 = sum(c.get_state("radix_launches") for c in profiled)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -591,6 +592,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    radix_per_frame = (sum(c.get_state("radix_launches") for c in profiled) - radix0) / float(args.steps)
     prof = merged_prof()
     # spread of the figure: the same K steps a few more times, outside the reported region
     repeats = []
@@ -887,6 +889,8 @@ def main():
         "repeat_ms_per_step": [round(x, 4) for x in repeats],
         "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
+        "radix_launches_per_step": round(radix_per_frame, 2),  # histogram + pass kernels of the built-in sort (ugrt_ctx_get_state)
+        "sort_rank_atomic": ctx.get_state("sort_rank_atomic"),
         "stages_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
         "stages_ms_per_step_alone_on_one_stream": alone,
         "warmup_steps_run": warm,

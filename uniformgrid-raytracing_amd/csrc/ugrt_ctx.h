@@ -133,6 +133,7 @@ struct ugrt_ctx {
 	DevBuf rs_state, rs_tmp[2];   // own radix sort: histogram rows + tickets, look-back words; ping-pong buffers
 	u32 rs_epoch = 0;             // tag of the last pass's look-back words
 	unsigned long long rs_launches = 0; // histogram + pass kernels enqueued so far (ugrt_ctx_get_state "radix_launches")
+	bool rs_prehist = false;      // the first pass's histogram rows hold the counts of a producer whose sort has not run yet
 	int rs_atomic_rank = -1;      // k_rs_selftest: 1 = LDS add-with-return serves equal addresses in lane order on this device
 	// per-triangle records {v0, v1-v0, v2-v0} (48 B), rewritten by every grid build; the tracers
 	// gather ONE record per reference instead of 3 indices + 3 vertices
@@ -207,7 +208,7 @@ int ugrt_prim_sort_pairs_rocprim(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const
 				 int end_bit);
 // ugrt_sort.hip
 int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
-			const u32 *n_dev = nullptr);
+			const u32 *n_dev = nullptr, bool prehist = false);
 int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,
 			   int end_bit);
 

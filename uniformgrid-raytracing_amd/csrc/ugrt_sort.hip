@@ -39,26 +39,6 @@
 
 typedef unsigned long long u64w; // look-back word: epoch << 32 | count
 
-// One more count of digit d in the workgroup's LDS histogram.  Neighbouring keys mostly share their digit (cell ids in
-// fill order, beams in candidate order), and lanes that add to one word -- or to one bank -- are served one after the
-// other.  The histogram is therefore kept RS_PRIV-fold, lane l adds to copy l % RS_PRIV, and the copies of a digit lie
-// next to each other (in different banks): 64 equal digits are four adds deep instead of 64.  (Sorting out the wave's
-// groups first -- one add per group by a leader lane -- was measured too: the scalar loop cost more than the adds.)
-#define RS_PRIV 16
-__device__ __forceinline__ void d_rs_count(u32 *s_h, u32 d, bool ok)
-{
-	if (ok)
-		atomicAdd(&s_h[d * RS_PRIV + (threadIdx.x & (RS_PRIV - 1u))], 1u);
-}
-__device__ __forceinline__ u32 d_rs_count_sum(const u32 *s_h, u32 d)
-{
-	u32 c = 0;
-#pragma unroll
-	for (u32 k = 0; k < RS_PRIV; k++)
-		c += s_h[d * RS_PRIV + ((k + d) & (RS_PRIV - 1u))]; // (rotated: the digit threads of a wave start in different banks)
-	return c;
-}
-
 // histogram of the first pass's digit (n_dev: the number of pairs when only the device knows it; n is then the
 // capacity the launch was sized for)
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, u32 dmask, u32 *hist, const u32 *__restrict__ n_dev)
@@ -391,7 +371,8 @@ static int rs_state(ugrt_ctx *ctx, u32 tiles)
 	const size_t bytes = (size_t)RS_HEAD_WORDS * 4 + look_words64 * 8;
 	if (bytes <= ctx->rs_state.cap)
 		return UGRT_OK;
-	// growing: between two sorts the head is all zeros (every pass cleans up behind itself), so nothing is carried over
+	// growing: between two sorts the head is all zeros (every pass cleans up behind itself); only the first pass's rows
+	// may hold what the producer of the coming sort's keys has counted
 	DevBuf old = ctx->rs_state;
 	ctx->rs_state = DevBuf();
 	int rc = ugrt_buf_reserve(ctx, ctx->rs_state, bytes);
@@ -411,6 +392,8 @@ static int rs_state(ugrt_ctx *ctx, u32 tiles)
 		ctx->rs_atomic_rank = h_bad == 0u ? 1 : 0;
 	}
 	if (old.p) {
+		if (ctx->rs_prehist)
+			UGRT_HIP(hipMemcpyAsync(ctx->rs_state.p, old.p, (size_t)RS_COPIES * RS_BINS * 4, hipMemcpyDeviceToDevice, ctx->stream));
 		UGRT_HIP(hipStreamSynchronize(ctx->stream)); // (a pass of the previous sort may still read the old words)
 		(void)hipFree(old.p);
 	}
@@ -418,11 +401,29 @@ static int rs_state(ugrt_ctx *ctx, u32 tiles)
 	return UGRT_OK;
 }
 
-// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
-// (n_dev != nullptr: the pair count lives on the device and n is the capacity the launches are sized for)
-int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
-			const u32 *n_dev)
+// the first pass's histogram rows, for the kernel that writes the next sort's keys (ugrt_rs_hist.h)
+int ugrt_sort_first_digit(ugrt_ctx *ctx, RsFirst *out)
 {
+	int rc = rs_state(ctx, 1);
+	if (rc)
+		return rc;
+	if (ctx->rs_prehist) // a producer ran and its sort never did (an error between them, or the producer is repeated)
+		UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, (size_t)RS_COPIES * RS_BINS * 4, ctx->stream));
+	ctx->rs_prehist = true;
+	out->hist = (u32 *)ctx->rs_state.p;
+	return UGRT_OK;
+}
+
+// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
+// (n_dev != nullptr: the pair count lives on the device and n is the capacity the launches are sized for;
+// prehist: the kernel that wrote the keys has counted their first digit, ugrt_sort_first_digit)
+int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
+			const u32 *n_dev, bool prehist)
+{
+	if (ctx->rs_prehist && (!prehist || n == 0)) { // counts of a producer whose sort does not run: forget them
+		UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, (size_t)RS_COPIES * RS_BINS * 4, ctx->stream));
+		ctx->rs_prehist = false;
+	}
 	if (n == 0)
 		return UGRT_OK;
 	if (n > ((size_t)1 << 30))
@@ -450,7 +451,9 @@ int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin
 	u64w *look = (u64w *)((u32 *)ctx->rs_state.p + RS_HEAD_WORDS);
 	u64w *look2 = look + (size_t)chunks * RS_CHUNK * RS_BINS;
 	auto bits_of_pass = [end_bit](int p) { return (u32)(end_bit - 8 * p) < 8u ? (u32)(end_bit - 8 * p) : 8u; };
-	{
+	if (prehist && ctx->rs_prehist) {
+		ctx->rs_prehist = false; // (the first pass reads the rows and its last workgroup clears them)
+	} else {
 		u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
 		hblocks = hblocks > 256u ? 256u : (hblocks ? hblocks : 1u);
 		hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, (1u << bits_of_pass(0)) - 1u, hist, n_dev);

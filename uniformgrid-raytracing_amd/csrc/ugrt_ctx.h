@@ -80,6 +80,7 @@ struct Grid {
 // layout of ugrt_ctx::d_small (u32 words of device scratch)
 #define UGRT_DSMALL_DDA_RAYS 2     // secondary rays in the DDA's ray list
 #define UGRT_DSMALL_WIDE 3         // wide triangles of the running build
+#define UGRT_DSMALL_DDA_RAYS_B 4   // the DDA's other ray counter (two in turn: a launch clears the next one's)
 #define UGRT_DSMALL_TICKET 8       // group ticket of the beam DDA
 #define UGRT_DSMALL_STATUS 14      // status bits of asynchronous calls
 #define UGRT_DSMALL_SHADOW_WORK 16 // u64 [2]: cull tests, staged candidates of the shadow pass (FLAG_COUNT_WORK)
@@ -146,6 +147,7 @@ struct ugrt_ctx {
 	DevBuf ubitmap;               // bounce: occupancy bitmap of the uniform grid's cells (1 bit per cell)
 	DevBuf dsort;                 // bounce, option dda_sort: keys + sorted keys + sorted list
 	DevBuf dsplit;                // bounce, split walks: work items, the groups' job history, merge state (ugrt_dda_walk.hip)
+	u32 dda_turn = 0;             // which of the two ray counters the last bounce used
 	u32 dsplit_rpw = 0, dsplit_turn = 0; // rays per wave the history was laid out for; launches since
 	DevBuf best;                  // u64 per pixel: (t bits << 32 | ref) for split cells
 	DevBuf rmap[2];               // ray sort ping-pong (2n u32 each)

@@ -53,9 +53,11 @@ __global__ __launch_bounds__(256) void k_dda_prepare(const int *__restrict__ act
 						      float *__restrict__ hit_t, int *__restrict__ hit_id,
 						      u32 *__restrict__ list, u32 *__restrict__ count,
 						      u32 *__restrict__ ticket, u32 pix_blocks, const u32 *__restrict__ span, u32 C,
-						      u32 *__restrict__ bitmap, u32 *__restrict__ chunk)
+						      u32 *__restrict__ bitmap, u32 *__restrict__ chunk, u32 *__restrict__ count_next)
 {
 	const int lane = threadIdx.x & 63;
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		*count_next = 0u; // (no kernel of this launch uses it; the next launch counts into it)
 	if (blockIdx.x >= pix_blocks) {
 		// the workgroups behind the pixels' write the window kernel's occupancy bitmap: bit c = span[c] != 0, one
 		// 64-bit word per wave and 64 cells
@@ -738,14 +740,17 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	const size_t list_cap = ((size_t)ctx->npix + DDA_PREP_SPAN - 1) / DDA_PREP_SPAN * DDA_PREP_SPAN;
 	if ((rc = ugrt_buf_reserve(ctx, ctx->wscan, list_cap * 4)))
 		return rc;
-	u32 *list = (u32 *)ctx->wscan.p, *dcount = ctx->d_small + UGRT_DSMALL_DDA_RAYS;
+	// (two ray counters in turn: a launch's prepare kernel clears the other one for the launch that follows -- no fill)
+	// (the turn is taken where the prepare kernel is launched: a call that fails before leaves both as they were)
+	const u32 turn = ctx->dda_turn ^ 1u;
+	u32 *list = (u32 *)ctx->wscan.p, *dcount = ctx->d_small + (turn ? UGRT_DSMALL_DDA_RAYS_B : UGRT_DSMALL_DDA_RAYS);
+	u32 *dcount_next = ctx->d_small + (turn ? UGRT_DSMALL_DDA_RAYS : UGRT_DSMALL_DDA_RAYS_B);
 	const bool use_rec = ctx->rec_valid && ctx->rec_verts == d_vertlist && ctx->rec_tris == d_trilist;
 	const float4 *rec = use_rec ? (const float4 *)ctx->trirec.p : (const float4 *)nullptr;
 	const bool counting = (ctx->cfg.flags & UGRT_FLAG_COUNT_WORK) != 0;
 	unsigned long long *dc = (unsigned long long *)(ctx->d_small + UGRT_DSMALL_DDA);
 	if (!counting)
 		ugrt_prof_begin(ctx, UGRT_ST_WORKLIST);
-	UGRT_HIP(hipMemsetAsync(dcount, 0, 4, ctx->stream));
 	// (the window kernel's occupancy bitmap is written by extra workgroups of the same launch)
 	const bool walk = ctx->opt[UGRT_OPT_DDA_KERNEL] <= 0;
 	const u32 ncell_all = (u32)g.dims[0] * (u32)g.dims[1] * (u32)g.dims[2];
@@ -774,7 +779,8 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		return rc;
 	hipLaunchKernelGGL(k_dda_prepare, dim3(pix_blocks + bm_blocks), dim3(256), 0, ctx->stream, d_active, ctx->p0, ctx->npix,
 			   ctx->cfg.width, d_hit_t, d_hit_id, list, dcount, ctx->d_small + UGRT_DSMALL_TICKET, pix_blocks, d_span,
-			   ncell_all, (u32 *)ctx->ubitmap.p, (u32 *)sp.chunk);
+			   ncell_all, (u32 *)ctx->ubitmap.p, (u32 *)sp.chunk, dcount_next);
+	ctx->dda_turn = turn;
 	if (!counting) {
 		ugrt_prof_end(ctx, UGRT_ST_WORKLIST);
 		ugrt_prof_begin(ctx, UGRT_ST_TRACE_DDA);

@@ -92,10 +92,12 @@ struct ChunkLoad {
 __global__ __launch_bounds__(PX_THREADS) void k_chunk_emit(const u32 *__restrict__ rstart,
 							    const u32 *__restrict__ rend,
 							    const u32 *__restrict__ incl, u32 ncell, u32 cap,
-							    u32 *__restrict__ prefix)
+							    u32 *__restrict__ prefix, u32 *__restrict__ host_total)
 {
 	const u32 total = incl[ncell - 1];
 	u32 k = blockIdx.x * PX_THREADS + threadIdx.x;
+	if (k == 0u)
+		*host_total = total; // h_numCudaBlocks, decision_data.h:264: straight into the pinned host word
 	if (k >= total || k >= cap)
 		return;
 	u32 lo = 0, hi = ncell - 1; // smallest c with incl[c] > k
@@ -169,11 +171,9 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 			maxchunks = prefix_capacity;
 		hipLaunchKernelGGL(k_chunk_emit, dim3((maxchunks + PX_THREADS - 1) / PX_THREADS), dim3(PX_THREADS), 0, st,
 				   (const u32 *)rstart, (const u32 *)rend, (const u32 *)ctx->cbase.p,
-				   ncell, prefix_capacity, d_prefix_map);
+				   ncell, prefix_capacity, d_prefix_map, ctx->h_pinned + UGRT_PIN_CHUNKS);
 	}
 	UGRT_HIP(hipGetLastError());
-	// h_numCudaBlocks, decision_data.h:264
-	UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_CHUNKS, (u32 *)ctx->cbase.p + (ncell - 1), 4, hipMemcpyDeviceToHost, st));
 	ugrt_prof_end(ctx, UGRT_ST_SORT_RAYS);
 	ctx->chunk_capacity = prefix_capacity;
 	ctx->chunk_prefix = d_prefix_map;

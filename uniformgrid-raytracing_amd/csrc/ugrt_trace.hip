@@ -993,16 +993,24 @@ __device__ __forceinline__ ShadowRay d_shadow_ray(const CamBlock &cam, const flo
 // waves take the beam's 64-ray runs in turn and keep per-lane minima and maxima; the lanes are folded once at the end
 // (one wave and a wave reduction per run took 49 us beside other frames once the beams were 2048 rays long).
 #define BOX_WAVES 4
+struct CullItem;
+// the cull pass's item table, written by the same launch (defined with the items below)
+__device__ void d_cull_items_fill(const u32 *__restrict__ iincl, const u32 *__restrict__ gincl, const u32 *__restrict__ span,
+				  const u32 *__restrict__ offset, u32 C, CullItem *__restrict__ items, u32 first, u32 stride);
 __global__ __launch_bounds__(64 * BOX_WAVES) void k_shadow_boxes(CamBlock cam, const u32 *__restrict__ gincl, u32 C,
 						     const u32 *__restrict__ rstart, const u32 *__restrict__ rend,
 						     const u32 *__restrict__ ray_pixels, const float *__restrict__ t_value_list,
 						     const float *__restrict__ ray_direction_list,
 						     const float *__restrict__ cmPt, GBox *__restrict__ boxes, u32 beam,
-						     u32 *__restrict__ zero, u32 nzero, float4 *__restrict__ sray)
+						     u32 *__restrict__ zero, u32 nzero, float4 *__restrict__ sray,
+						     const u32 *__restrict__ iincl, const u32 *__restrict__ span,
+						     const u32 *__restrict__ offset, CullItem *__restrict__ citems)
 {
 	__shared__ float s_box[BOX_WAVES][6];
 	for (u32 z = blockIdx.x * (64u * BOX_WAVES) + threadIdx.x; z < nzero; z += gridDim.x * (64u * BOX_WAVES))
 		zero[z] = 0; // candidate run starts/ends per beam, written after the pair sort
+	// (the cull pass's items depend on the same two scans as the boxes: listed here instead of by a launch of their own)
+	d_cull_items_fill(iincl, gincl, span, offset, C, citems, blockIdx.x * (64u * BOX_WAVES) + threadIdx.x, gridDim.x * (64u * BOX_WAVES));
 	const u32 total = gincl[C - 1];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const float cm[3] = { cmPt[0], cmPt[1], cmPt[2] };
@@ -1189,12 +1197,11 @@ __device__ __forceinline__ CullItem d_cull_item(const u32 *__restrict__ iincl, c
 // The items as a table (the first CULL_TABLE of them; the bench frame has 27 k): the kernel reads an item with one
 // scalar load instead of a search and four dependent loads at the head of every item
 #define CULL_TABLE (1u << 20)
-__global__ __launch_bounds__(WL_THREADS) void k_cull_items(const u32 *__restrict__ iincl, const u32 *__restrict__ gincl,
-							    const u32 *__restrict__ span, const u32 *__restrict__ offset, u32 C,
-							    CullItem *__restrict__ items)
+__device__ void d_cull_items_fill(const u32 *__restrict__ iincl, const u32 *__restrict__ gincl, const u32 *__restrict__ span,
+				  const u32 *__restrict__ offset, u32 C, CullItem *__restrict__ items, u32 first, u32 stride)
 {
-	const u32 it = blockIdx.x * WL_THREADS + threadIdx.x;
-	if (it < CULL_TABLE && it < iincl[C - 1])
+	const u32 total = iincl[C - 1] < CULL_TABLE ? iincl[C - 1] : CULL_TABLE;
+	for (u32 it = first; it < total; it += stride)
 		items[it] = d_cull_item(iincl, gincl, span, offset, C, it);
 }
 
@@ -1722,15 +1729,12 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		if ((rc = ugrt_scan_launch<true>(ctx, items, iincl, C, ScanTailNone())))
 			return rc;
 	}
+	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * sizeof(CullItem))))
+		return rc;
 	hipLaunchKernelGGL(k_shadow_boxes, dim3(launch_blocks_for((u32)maxg)), dim3(64 * BOX_WAVES), 0, st, ctx->cam,
 			   (const u32 *)gincl, C, (const u32 *)rstart, (const u32 *)rend, (const u32 *)v1, d_t_value,
 			   d_ray_dir, d_cam_position, boxes, beam, pstart, (u32)(2 * maxg + maxg * (beam / 64u)),
-			   (float4 *)ctx->sray.p);
-	UGRT_HIP(hipGetLastError());
-	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * sizeof(CullItem))))
-		return rc;
-	hipLaunchKernelGGL(k_cull_items, dim3(CULL_TABLE / WL_THREADS), dim3(WL_THREADS), 0, st, (const u32 *)iincl,
-			   (const u32 *)gincl, d_span, d_offset, C, (CullItem *)ctx->citem.p);
+			   (float4 *)ctx->sray.p, (const u32 *)iincl, d_span, d_offset, (CullItem *)ctx->citem.p);
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_SHADOW_PREP);
 	u32 sbits = ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] >= 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_SIZEBITS] : 4u;
@@ -1741,7 +1745,8 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// the previous pass's counts plus a quarter, the kernels take the real counts from the device, and counts
 	// beyond the capacities raise a status bit instead (UGRT_EOVERFLOW at the next synchronisation).
 	u32 *pcount = ctx->d_small + UGRT_DSMALL_PAIRS; // right behind the work counters: cleared with them
-	u32 *status = ctx->d_small + UGRT_DSMALL_STATUS, *pg = ctx->d_small + UGRT_DSMALL_SHADOW, *report = pg + 2;
+	// (the report is written by the kernels straight into the pinned host words: no copy behind the pass)
+	u32 *status = ctx->d_small + UGRT_DSMALL_STATUS, *pg = ctx->d_small + UGRT_DSMALL_SHADOW, *report = ctx->h_pinned + UGRT_PIN_SHADOW;
 	if (ctx->shadow_async_pending) { // what the last asynchronous pass needed (possibly a frame old)
 		ctx->est_pairs = ctx->h_pinned[UGRT_PIN_SHADOW];
 		ctx->est_beams = ctx->h_pinned[UGRT_PIN_SHADOW + 1];
@@ -1909,12 +1914,9 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt, xslices);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
-	// ONE copy per pass: {pairs, beams} as found (asynchronous form: what the next pass is sized by; the waiting form
-	// knows them already and keeps the host's words), the status word, the work counters (ugrt_stats_get)
-	if (async)
-		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW, report, 32, hipMemcpyDeviceToHost, st));
-	else
-		UGRT_HIP(hipMemcpyAsync(ctx->h_pinned + UGRT_PIN_SHADOW + 2, report + 2, 24, hipMemcpyDeviceToHost, st));
+	// (the pass's report -- {pairs, beams} as found in the asynchronous form: what the next pass is sized by; the status
+	// word; the work counters of ugrt_stats_get -- is in the pinned host words when the stream has got this far: the
+	// compaction and the exact pass write it there themselves)
 	return UGRT_OK;
 }
 

@@ -609,6 +609,7 @@ def main():
     split_stats = None
     # latency: the same K steps with ONE frame in flight (every frame is finished before the next one is started)
     latency_ms = None
+    latency_repeats = []
     if len(renderers) > 1:
         user_waves = [kv for kv in opts if kv.startswith(("dda_blocks=", "shadow_waves=", "dda_rays_per_wave=", "dda_split="))]
         if renderers[0].aux is not None and not user_waves:
@@ -625,6 +626,15 @@ def main():
         renderers[0].synchronize()
         torch.cuda.synchronize()
         latency_ms = (time.perf_counter() - r0) / args.steps * 1e3
+        for _ in range(min(args.repeats, 2)):  # (spread of the one-frame figure)
+            r0 = time.perf_counter()
+            for _ in range(args.steps):
+                renderers[0].display(setup, frame_cnt=1, shadows=True, reflect=reflect)
+                gather.gather(renderers[0].image)
+            gather.finish()
+            renderers[0].synchronize()
+            torch.cuda.synchronize()
+            latency_repeats.append((time.perf_counter() - r0) / args.steps * 1e3)
         # what the bounce's split walks did in the last of those frames
         if reflect:
             c0 = renderers[0].aux if renderers[0].aux is not None else renderers[0].ctx
@@ -887,6 +897,7 @@ def main():
         "verified_against_single_context_frame": verified,
         "verify_mismatches_per_renderer": verify_detail,
         "repeat_ms_per_step": [round(x, 4) for x in repeats],
+        "repeat_ms_per_step_one_frame_in_flight": [round(x, 4) for x in latency_repeats],
         "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),
         "radix_launches_per_step": round(radix_per_frame, 2),  # histogram + pass kernels of the built-in sort (ugrt_ctx_get_state)

@@ -211,7 +211,8 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * "shadow_waves": number of persistent single-wave workgroups of the bounce, the primary tracer and the two
  * shadow kernels (the primary tracer and the exact shadow pass run one wave per work item by default, "primary_xcd_run" /
  * "shadow_xcd_run" neighbouring items per XCD in turn; "primary_waves" set / "shadow_xcd_run" 0 restore their persistent
- * forms; "shadow_waves" is always the cull pass's).
+ * forms; "shadow_waves" is always the cull pass's; "primary_centre" 0 = the primary tracer's runs of items start in
+ * list order instead of from the middle of the list outwards).
  * "async_build" 1: the grid builds and ugrt_trace_shadow stop waiting for the device.  The reference reads
  * total_triangles back to size its lists (frustum_grid.h:254); here the second and later builds of a grid size
  * buffers and launches by what the build before needed plus a quarter, every kernel takes the real counts from

@@ -443,7 +443,7 @@ def test_bounce_split_history_survives_toggles(ugrt, O, torch):
     assert cut >= 1, cut  # (a changed camera or rays-per-wave setting leaves launches without a usable history)
 
 
-LAUNCH_SHAPES = [("primary_waves", 64), ("primary_waves", 4096), ("primary_xcd_run", 0), ("primary_xcd_run", 1),
+LAUNCH_SHAPES = [("primary_centre", 0), ("primary_waves", 64), ("primary_waves", 4096), ("primary_xcd_run", 0), ("primary_xcd_run", 1),
                  ("primary_xcd_run", 7), ("primary_xcd_run", 4096), ("shadow_xcd_run", 0), ("shadow_xcd_run", 1),
                  ("shadow_xcd_run", 4096), ("shadow_waves", 64), ("primary_order", 0), ("primary_chunk", 4),
                  ("primary_chunk", 64), ("primary_seg", 64), ("shadow_beam", 64), ("shadow_beam", 8192), ("shadow_xseg", 64),

@@ -47,6 +47,7 @@ enum {
 	UGRT_OPT_DDA_SPLIT_SEGMENTS, // "dda_split_segments": segments a group is cut into at most (1..4; 1 = none is cut, the long groups are only started first)
 	UGRT_OPT_PRIMARY_XCD_RUN,  // "primary_xcd_run": primary tracer, one wave per item: neighbouring items per XCD in turn (default 128; 0 = one)
 	UGRT_OPT_SHADOW_XCD_RUN,   // "shadow_xcd_run": exact shadow pass: one wave per item, this many neighbouring items per XCD in turn (default 128); 0 = the persistent waves of round 2
+	UGRT_OPT_PRIMARY_CENTRE,   // "primary_centre": primary tracer, one wave per item: 0 = the runs of items in list order (default 1: from the middle of the list outwards)
 	UGRT_OPT_SORT_RANK,        // "sort_rank": radix pass: 0 = ranks by ballots, 1 / default = by LDS atomics where the device's self-test allows it
 	UGRT_OPT_COUNT
 };

@@ -129,7 +129,9 @@ __device__ __forceinline__ u32 d_axis_shift(m64 a0, m64 a1)
 		}                                                             \
 	} while (0)
 
-template <bool COUNT, bool REC>
+// SPLIT false: the kernel without split walks (no history is read or written): every `sp.` below is then a null the
+// compiler folds away -- 40 scalar registers, the redo / segment tests of every window and the spills that came with them
+template <bool COUNT, bool REC, bool SPLIT>
 __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__restrict__ value_list,
 							const u32 *__restrict__ span, const u32 *__restrict__ offset,
 							const u32 *__restrict__ bitmap, const float *__restrict__ verts,
@@ -137,8 +139,9 @@ __global__ __launch_bounds__(64, 3) void k_trace_dda_walk(DGrid g, const u32 *__
 							const float *__restrict__ rays, const u32 *__restrict__ list,
 							const u32 *__restrict__ count_p, float *__restrict__ hit_t,
 							int *__restrict__ hit_id, unsigned long long *__restrict__ counters,
-							u32 RPW, u32 CULL_MIN, u32 CULL_WORK, u32 *__restrict__ ticket, WalkSplit sp)
+							u32 RPW, u32 CULL_MIN, u32 CULL_WORK, u32 *__restrict__ ticket, WalkSplit sp_in)
 {
+	const WalkSplit sp = SPLIT ? sp_in : WalkSplit{ nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr, nullptr };
 	__shared__ u32 s_cell[WK_AHEAD][64];    // cell of (step, ray); written for occupied cells only
 	__shared__ float s_tnext[WK_AHEAD][64]; // exit parameter of (step, ray); the entry of step q is the exit of q - 1
 	__shared__ __attribute__((aligned(16))) float s_surv[64 * TRI_STRIDE]; // survivors of a batch: 9 floats + list position
@@ -943,10 +946,19 @@ int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list,
 				   RPW, sp, sph.items, sph.cut, sph.hdr_prev, sph.hdr_next, sph.load, sph.force, sph.maxg, (u32)blocks, sph.maxseg);
 		UGRT_HIP(hipGetLastError());
 	}
-#define WK_LAUNCH(CNTV, RECV)                                                                                          \
-	hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span, \
-			   d_offset, (const u32 *)bitmap, d_vertlist, d_trilist, rec, d_rays, list, dcount, d_hit_t, d_hit_id, \
-			   counters, RPW, CULL_MIN, CULL_WORK, ticket, sp)
+	// (a context without split walks -- option dda_split 0, or a launch that cannot keep a history -- runs the lean kernel)
+	const bool split = sp.items || sp.fb || sp.walked || sp.cut;
+#define WK_LAUNCH(CNTV, RECV)                                                                                                  \
+	do {                                                                                                                   \
+		if (split)                                                                                                     \
+			hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV, true>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, \
+					   d_span, d_offset, (const u32 *)bitmap, d_vertlist, d_trilist, rec, d_rays, list, dcount,  \
+					   d_hit_t, d_hit_id, counters, RPW, CULL_MIN, CULL_WORK, ticket, sp);                       \
+		else                                                                                                           \
+			hipLaunchKernelGGL((k_trace_dda_walk<CNTV, RECV, false>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, \
+					   d_span, d_offset, (const u32 *)bitmap, d_vertlist, d_trilist, rec, d_rays, list, dcount,  \
+					   d_hit_t, d_hit_id, counters, RPW, CULL_MIN, CULL_WORK, ticket, sp);                       \
+	} while (0)
 	if (counting) {
 		if (rec)
 			WK_LAUNCH(true, true);

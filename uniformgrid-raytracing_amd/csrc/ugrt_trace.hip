@@ -204,7 +204,19 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 		first = d_xcd_block();
 	} else if (SLICES > 1u) {
 		const u32 run = SLICES >> 1, j = blockIdx.x >> 3;
-		first = ((j / run) * 8u + (blockIdx.x & 7u)) * run + j % run;
+		u32 g = j / run; // round of eight runs
+		if (SLICES & 1u) {
+			// Centre out: the rounds are taken from the middle of the list outwards (mid, mid + 1, mid - 1, ...).  The list is
+			// in screen order, column by column, and the cells that cost most (the long lists a camera looks at) sit around the
+			// middle of the view: in list order their items start half-way through the launch and ARE its tail (the longest
+			// last four times the mean: profiles/r03_primary_timeline.txt); started first they are over when the cheap ones run out.
+			const u32 G = (nitems + 8u * run - 1u) / (8u * run);
+			if (g >= G)
+				return;
+			const u32 mid = (G - 1u) >> 1;
+			g = (g & 1u) ? mid + ((g + 1u) >> 1) : mid - (g >> 1);
+		}
+		first = (g * 8u + (blockIdx.x & 7u)) * run + j % run;
 	}
 	for (u32 it = first; it < nitems; it += gridDim.x) {
 		const WItem w = items[it];
@@ -707,7 +719,8 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 #define LAUNCH_PRIMARY(REC_, COUNT_)                                                                                  \
 	hipLaunchKernelGGL((k_trace_primary<REC_, COUNT_>), dim3(pwaves), dim3(64), 0, st, ctx->cam, tex,              \
 			   (const WItem *)items, (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist, \
-			   (const float4 *)(REC_ ? ctx->trirec.p : nullptr), out, (u64 *)ctx->best.p, ctx->p0, pc, p_order, p_chunk, p_slices ? 1u : p_run << 1)
+			   (const float4 *)(REC_ ? ctx->trirec.p : nullptr), out, (u64 *)ctx->best.p, ctx->p0, pc, p_order, p_chunk, \
+			   p_slices ? 1u : (p_run << 1) | (p_run && ctx->opt[UGRT_OPT_PRIMARY_CENTRE] != 0 ? 1u : 0u))
 	if (counting) {
 		UGRT_HIP(hipMemsetAsync(pc, 0, UGRT_PRIMARY_STATS * 8, st));
 		if (use_rec)

@@ -257,6 +257,14 @@ int ugrt_grid_get_slabs(ugrt_ctx *ctx, int which, ugrt_slab_info *out);
 int ugrt_ctx_set_face_window(ugrt_ctx *ctx, int begin, int end);
 int ugrt_grid_merge_shards(ugrt_ctx *ctx, int which, int nparts, const unsigned *const *d_keys,
 			   const unsigned *const *d_vals, const unsigned *const *d_span, const unsigned *counts);
+/* Two grid builds that depend on the geometry only (a frame's light grid and uniform grid) in shared sort launches:
+ * between _begin and _end each ugrt_grid_build_* call of this context enqueues its count, scan and fill and returns;
+ * _end sorts the (at most two) reference lists together -- one histogram kernel and one kernel per pass level for
+ * both -- and completes the builds.  Results are those of two separate builds.  Only builds in the asynchronous form
+ * ("async_build") are deferred; any other is built at once.  The grids of the batch must not be used (traced,
+ * queried, waited for by another stream) before _end has returned.  No reference counterpart. */
+int ugrt_grid_build_batch_begin(ugrt_ctx *ctx);
+int ugrt_grid_build_batch_end(ugrt_ctx *ctx);
 /* with UGRT_FLAG_STATIC_GEOMETRY: the vertex or face array was rewritten by the caller */
 int ugrt_geometry_changed(ugrt_ctx *ctx);
 /* cudppSort(plan, keys, values, bits, n) with CUDPP_SORT_RADIX on (uint key, uint value) pairs

@@ -177,14 +177,19 @@ void display() // main.cu:59-302
 		HIP_CHECK(hipEventRecord(ev_geometry, g_main));
 		HIP_CHECK(hipStreamWaitEvent(g_side, ev_geometry, 0));
 		UGRT_CHECK(ugrt_upload_camera(g_aux, light_cam.camcoords));
+		// (with the bounce both grids are built in one batch: their reference lists are sorted in shared launches)
+		if (P.reflect)
+			UGRT_CHECK(ugrt_grid_build_batch_begin(g_aux));
 		UGRT_CHECK(ugrt_grid_build_spherical(g_aux, model->d_facelist, model->d_vertexlist, model->num_faces, (float)M_PI,
 						     (float)M_PI));
-		HIP_CHECK(hipEventRecord(ev_light_grid, g_side));
-		lightGrid.fetch(g_aux, UGRT_GRID_SPHERICAL);
 		if (P.reflect) {
 			UGRT_CHECK(ugrt_grid_build_uniform(g_aux, model->d_facelist, model->d_vertexlist, model->num_faces, bbmin, bbmax));
-			uniGrid.fetch(g_aux, UGRT_GRID_UNIFORM);
+			UGRT_CHECK(ugrt_grid_build_batch_end(g_aux));
 		}
+		HIP_CHECK(hipEventRecord(ev_light_grid, g_side));
+		lightGrid.fetch(g_aux, UGRT_GRID_SPHERICAL);
+		if (P.reflect)
+			uniGrid.fetch(g_aux, UGRT_GRID_UNIFORM);
 	}
 	fGrid->buildGrid(model->d_facelist, model->d_vertexlist); // build_frustum_grid, main.cu:133
 	fTracer->trace(fGrid->d_triangle_value_list, fGrid->d_span, fGrid->d_offset, dData->d_primary_ray_normal,

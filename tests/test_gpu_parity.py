@@ -996,6 +996,64 @@ def test_full_size_bench_workload(ugrt, O, torch):
     assert (pr["id"][a:b] >= 0).sum() > 1000 and want["is_shadowed"][a:b].sum() > 100
 
 
+@pytest.mark.parametrize("name,W,H,lg,ud", [("crash", 384, 216, (64, 64), (32, 32, 16)), ("hall", 256, 256, (128, 128), (64, 64, 32))])
+def test_batched_light_and_uniform_builds(ugrt, O, torch, name, W, H, lg, ud):
+    """ugrt_grid_build_batch_begin / _end: the light grid's and the uniform grid's reference lists are sorted in shared
+    launches (one histogram kernel, one kernel per pass level; the list with fewer passes drops out).  Frame 0 builds
+    both in the waiting form (nothing is deferred), the later ones in the asynchronous form as a batch; after every
+    frame both grids' arrays equal the CPU restatement's element for element, and so does the frame.  Then the same
+    with the batch switched off, with ballot ranks and 4096-pair tiles, and with one build of the batch only."""
+    s = scene(ugrt, name)
+    setup = setup_for(ugrt, s, "ref")
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud, all_chunks=True)
+    cx = ugrt.Context(W, H, light_grid=lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS, uniform_dims=ud)
+    r = ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], overlap=True, helper_thread=False)
+    for c in (r.ctx, r.aux):
+        c.set_option("async_build", 1)
+    before = r.aux.get_state("radix_launches")
+    per_frame = []
+    for k, (batch, rank, items) in enumerate([(True, -1, -1), (True, -1, -1), (True, -1, -1), (False, -1, -1), (True, 0, 8), (True, -1, 16)]):
+        r.batch_builds = batch
+        r.aux.set_option("sort_rank", rank)
+        r.aux.set_option("sort_items", items)
+        r.display(setup, shadows=True, reflect=True)
+        r.synchronize()
+        now = r.aux.get_state("radix_launches")
+        per_frame.append(now - before)
+        before = now
+        what = "frame %d (batch %r)" % (k, batch)
+        for which, g in ((ugrt.GRID_SPHERICAL, "lgrid"), (ugrt.GRID_UNIFORM, "ugrid")):
+            value, key, span, offset, gi = r.aux.grid_arrays(which)
+            np.testing.assert_array_equal(u32(key), want[g]["keys"], err_msg=what)
+            np.testing.assert_array_equal(u32(value), want[g]["vals"], err_msg=what)
+            np.testing.assert_array_equal(u32(span), want[g]["span"], err_msg=what)
+        np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"], err_msg=what)
+        np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want["hit_id"], err_msg=what)
+        np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"], err_msg=what)
+    # a batch is its passes once (the longer list's) and one histogram kernel; apart, the lists' passes add up
+    lb, ub = (bits_for_cells(lg[0] * lg[1]) + 7) // 8, (bits_for_cells(ud[0] * ud[1] * ud[2]) + 7) // 8
+    assert per_frame[2] == max(lb, ub) + 1 and per_frame[3] == lb + ub + 2, (per_frame, lb, ub)
+    # one build inside a batch, and an empty batch
+    r.aux.grid_build_batch_begin()
+    r.aux.grid_build_uniform(r.d_faces, r.d_verts, r.F, r.bbmin, r.bbmax)
+    r.aux.grid_build_batch_end()
+    r.aux.grid_build_batch_begin()
+    r.aux.grid_build_batch_end()
+    r.aux.synchronize()
+    value, key, span, offset, gi = r.aux.grid_arrays(ugrt.GRID_UNIFORM)
+    np.testing.assert_array_equal(u32(key), want["ugrid"]["keys"])
+    np.testing.assert_array_equal(u32(value), want["ugrid"]["vals"])
+    with pytest.raises(ugrt.UgrtError):
+        r.aux.grid_build_batch_end()  # no batch is open
+
+
+def bits_for_cells(c):
+    b = 1
+    while (1 << b) < c:
+        b += 1
+    return b
+
+
 def test_bench_setting_four_renderers_in_flight(ugrt, O, torch):
     """The setting bench.py times by default, built here piece by piece: 1 M triangles at 1920x1080, FOUR renderers
     (each two contexts on two streams fed by this one host thread: overlap=True, helper_thread=False), builds and

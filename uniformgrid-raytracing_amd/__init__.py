@@ -128,6 +128,8 @@ PROTOTYPES = {
     "ugrt_grid_build_perspective": (C.c_int, [_P, _P, _P, C.c_int]),
     "ugrt_grid_build_spherical": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_float]),
     "ugrt_grid_build_uniform": (C.c_int, [_P, _P, _P, C.c_int, _F3, _F3]),
+    "ugrt_grid_build_batch_begin": (C.c_int, [_P]),
+    "ugrt_grid_build_batch_end": (C.c_int, [_P]),
     "ugrt_grid_get_info": (C.c_int, [_P, C.c_int, C.POINTER(GridInfo)]),
     "ugrt_grid_get_slabs": (C.c_int, [_P, C.c_int, C.POINTER(SlabInfo)]),
     "ugrt_ctx_set_face_window": (C.c_int, [_P, C.c_int, C.c_int]),

@@ -662,8 +662,13 @@ static int bits_for(u32 C)
 // written out of bounds) and a status bit is raised, which the host sees at its next synchronisation
 // (UGRT_EOVERFLOW; the following build of the grid runs synchronously and sizes the buffers exactly).
 // ---------------------------------------------------------------------------
-static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, int ylo, int yhi)
+// (three parts: everything before the sort, the sort, everything behind it -- so that the builds of a batch,
+// ugrt_grid_build_batch_begin / _end, can share the launches of their sorts)
+static int build_async_begin(ugrt_ctx *ctx, AsyncBuild &b)
 {
+	Grid &G = *b.G;
+	const int F = b.F, ny = b.ny, nz = b.nz, ylo = b.ylo, yhi = b.yhi;
+	const u32 C = b.C;
 	hipStream_t st = ctx->stream;
 	const int gi = (int)(&G - ctx->grid);
 	int rc;
@@ -707,8 +712,7 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	capR = (G.key[0].cap < G.val[0].cap ? G.key[0].cap : G.val[0].cap) / 4;
 	if (capR > 0xFFFFFFF0ull)
 		capR = 0xFFFFFFF0ull;
-	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
-	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
+	u32 *k0 = (u32 *)G.key[0].p, *v0 = (u32 *)G.val[0].p;
 	u32 *rw = ctx->d_small + UGRT_DSMALL_RW + 2 * gi, *status = ctx->d_small + UGRT_DSMALL_STATUS;
 	// (written by the build's kernels straight into the pinned host words: no copy behind the build)
 	u32 *report = ctx->h_pinned + UGRT_PIN_REPORT + 4 * gi;
@@ -717,33 +721,73 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	// reference of the launch, so a count between the two would leave references unfilled and unsorted.
 	const u32 launchRn = estRn + estRn / 4u + 65536u < capRn ? estRn + estRn / 4u + 65536u : capRn;
 	BuildCheck chk = { (const u32 *)G.scan.p + (F - 1), launchRn, capW, capR, active, rw, status, report };
-	WideBox wb;
-	wb.W = 0;
-	wb.ny = (u32)ny;
-	wb.nz = (u32)nz;
-	wb.ylo = (u32)ylo;
-	wb.yhi = (u32)yhi;
-	wb.rw = rw;
 	const u32 nparts = (launchRn + BUILD_THREADS - 1) / BUILD_THREADS;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, chk);
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1;
 	hipLaunchKernelGGL(k_fill, dim3(nparts < FILL_MAX_BLOCKS ? nparts : FILL_MAX_BLOCKS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, (const Rng *)G.rng.p, (const u32 *)G.parts.p, 0u, ny, nz, k0, v0, (u32 *)G.span.p,
 			   2u * C + 1u, (const u32 *)rw);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 	UGRT_HIP(hipGetLastError());
+	b.launchRn = launchRn, b.capW = capW, b.capR = capR, b.active = active, b.no_wide = no_wide, b.nparts = nparts;
+	return UGRT_OK;
+}
+
+// the sort of one or two begun builds, in shared launches
+static int build_async_sort(ugrt_ctx *ctx, AsyncBuild *b, int n)
+{
+	int rc = UGRT_OK;
+	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-	rc = own_sort ? ugrt_sort_pairs_u32(ctx, k0, k1, v0, v1, launchRn, bits_for(C), rw)
-		      : ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, launchRn, bits_for(C), rw);
+	RsJob jobs[2];
+	for (int i = 0; i < n; i++) {
+		Grid &G = *b[i].G;
+		const int gi = (int)(&G - ctx->grid);
+		jobs[i] = RsJob{ (const u32 *)G.key[0].p, (const u32 *)G.val[0].p, (u32 *)G.key[1].p, (u32 *)G.val[1].p, b[i].launchRn,
+				 bits_for(b[i].C), (const u32 *)(ctx->d_small + UGRT_DSMALL_RW + 2 * gi) };
+	}
+	if (own_sort) {
+		rc = ugrt_sort_pairs_batch(ctx, jobs, n);
+	} else {
+		for (int i = 0; i < n && !rc; i++)
+			rc = ugrt_prim_sort_pairs(ctx, jobs[i].kin, jobs[i].kout, jobs[i].vin, jobs[i].vout, jobs[i].n, jobs[i].end_bit, jobs[i].n_dev);
+	}
 	if (rc)
 		return rc;
-	if (!no_wide)
-		hipLaunchKernelGGL(k_wide_rank, dim3((capW + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
-				   (const u32 *)wl, 0u, wsorted, (const u32 *)rw);
+	for (int i = 0; i < n; i++) {
+		Grid &G = *b[i].G;
+		const int gi = (int)(&G - ctx->grid);
+		if (!b[i].no_wide)
+			hipLaunchKernelGGL(k_wide_rank, dim3((b[i].capW + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0, ctx->stream,
+					   (const u32 *)G.wide.p, 0u, (u32 *)G.wide.p + b[i].F, (const u32 *)(ctx->d_small + UGRT_DSMALL_RW + 2 * gi));
+	}
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}
+
+static int build_async_end(ugrt_ctx *ctx, AsyncBuild &b)
+{
+	Grid &G = *b.G;
+	const int F = b.F;
+	const u32 C = b.C;
+	hipStream_t st = ctx->stream;
+	const int gi = (int)(&G - ctx->grid);
+	int rc;
+	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
+	u32 *wsorted = (u32 *)G.wide.p + F;
+	u32 *rw = ctx->d_small + UGRT_DSMALL_RW + 2 * gi, *status = ctx->d_small + UGRT_DSMALL_STATUS;
+	u32 *report = ctx->h_pinned + UGRT_PIN_REPORT + 4 * gi;
+	const bool no_wide = b.no_wide;
+	WideBox wb;
+	wb.W = 0;
+	wb.ny = (u32)b.ny;
+	wb.nz = (u32)b.nz;
+	wb.ylo = (u32)b.ylo;
+	wb.yhi = (u32)b.yhi;
+	wb.rw = rw;
+	const u32 nparts = b.nparts;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
 	u32 *cstart = (u32 *)G.span.p + C, *used = cstart + C;
 	hipLaunchKernelGGL(k_bounds, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, 0u, cstart, (u32 *)G.span.p,
@@ -772,12 +816,63 @@ static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int 
 	}
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_BOUNDS);
-	G.R = no_wide ? launchRn : (u32)capR; // an upper bound; the exact count travels to pinned memory with the next lines
+	G.R = no_wide ? b.launchRn : (u32)b.capR; // an upper bound; the exact count is in the pinned report words once the stream has got here
 	G.r_exact = false;
-	G.active_cells = active;
+	G.active_cells = b.active;
 	G.async_pending = true;
 	G.valid = true;
 	return UGRT_OK;
+}
+
+static int build_common_async(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, int ylo, int yhi)
+{
+	AsyncBuild b = {};
+	b.G = &G, b.F = F, b.C = C, b.ny = ny, b.nz = nz, b.ylo = ylo, b.yhi = yhi;
+	int rc = build_async_begin(ctx, b);
+	if (rc)
+		return rc;
+	// inside ugrt_grid_build_batch_begin / _end the build stops here: its sort shares its launches with the next build's
+	if (ctx->batch_open && ctx->nbatch < 2) {
+		ctx->batch[ctx->nbatch++] = b;
+		return UGRT_OK;
+	}
+	if ((rc = build_async_sort(ctx, &b, 1)))
+		return rc;
+	return build_async_end(ctx, b);
+}
+
+// Two grid builds that depend on the geometry only (the light grid and the uniform grid of a frame) between
+// ugrt_grid_build_batch_begin and _end: each ugrt_grid_build_* call in between enqueues its count, scan and fill and
+// returns; _end sorts both reference lists in shared launches (one histogram kernel, one kernel per pass level) and
+// completes the builds.  A build that cannot run in the asynchronous form (the first of a grid, after an overflow,
+// slabs > 1) is simply built at once.  Until _end has returned the grids of the batch must not be used.
+extern "C" int ugrt_grid_build_batch_begin(ugrt_ctx *ctx)
+{
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_batch_begin: null context");
+	if (ctx->batch_open)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_batch_begin: a batch is open already");
+	ctx->batch_open = true;
+	ctx->nbatch = 0;
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_grid_build_batch_end(ugrt_ctx *ctx)
+{
+	if (!ctx)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_batch_end: null context");
+	if (!ctx->batch_open)
+		return ugrt_fail(UGRT_EINVAL, "grid_build_batch_end: no batch is open");
+	ctx->batch_open = false;
+	const int n = ctx->nbatch;
+	ctx->nbatch = 0;
+	if (n == 0)
+		return UGRT_OK;
+	UGRT_HIP(hipSetDevice(ctx->device));
+	int rc = build_async_sort(ctx, ctx->batch, n);
+	for (int i = 0; i < n && !rc; i++)
+		rc = build_async_end(ctx, ctx->batch[i]);
+	return rc;
 }
 
 // shared tail of the three builders: sizes/rng/wide list are filled, ny/nz give the key layout,

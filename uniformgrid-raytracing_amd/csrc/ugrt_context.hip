@@ -138,8 +138,10 @@ extern "C" void ugrt_ctx_destroy(ugrt_ctx *ctx)
 		}
 	buf_free(ctx->temp);
 	buf_free(ctx->rs_state);
-	buf_free(ctx->rs_tmp[0]);
-	buf_free(ctx->rs_tmp[1]);
+	for (int j = 0; j < 2; j++) {
+		buf_free(ctx->rs_tmp[j][0]);
+		buf_free(ctx->rs_tmp[j][1]);
+	}
 	buf_free(ctx->trirec);
 	buf_free(ctx->witems);
 	buf_free(ctx->wscan);

@@ -114,6 +114,15 @@ struct Grid {
 static_assert(UGRT_DSMALL_DDA + 2 * UGRT_DDA_STATS <= UGRT_DSMALL_RW, "the DDA's counters run into the build counts");
 static_assert(UGRT_DSMALL_REPORT + 12 <= UGRT_DSMALL_SHADOW && UGRT_DSMALL_SHADOW + 10 <= UGRT_DSMALL_PRIMARY && UGRT_DSMALL_PRIMARY + 2 * UGRT_PRIMARY_STATS <= UGRT_DSMALL_WORDS && UGRT_PIN_SHADOW + 8 <= UGRT_PIN_WORDS && UGRT_PIN_REPORT + 12 <= UGRT_PIN_SHADOW, "scratch layout");
 
+// an asynchronous grid build between its fill and its sort (ugrt_build.hip: build_async_begin / _sort / _end)
+struct AsyncBuild {
+	Grid *G;
+	int F, ny, nz, ylo, yhi;
+	u32 C, launchRn, capW, nparts;
+	unsigned long long capR, active;
+	bool no_wide;
+};
+
 struct ProfPair {
 	hipEvent_t a, b;
 };
@@ -132,8 +141,12 @@ struct ugrt_ctx {
 	DevBuf temp;                  // rocPRIM temporary storage
 	DevBuf scan_state;            // own scan: ticket + done counter (64 B), then one epoch-tagged state word per tile
 	u32 scan_epoch = 0;           // tag of the last scan's state words
-	DevBuf rs_state, rs_tmp[2];   // own radix sort: histogram rows + tickets, look-back words; ping-pong buffers
+	DevBuf rs_state, rs_tmp[2][2]; // own radix sort: histogram rows + tickets, look-back words; ping-pong buffers per list of a batch
+	u32 rs_tiles = 0;             // tiles per list the look-back words are laid out for
 	u32 rs_epoch = 0;             // tag of the last pass's look-back words
+	bool batch_open = false;      // ugrt_grid_build_batch_begin: the builds that follow stop in front of their sorts
+	int nbatch = 0;
+	AsyncBuild batch[2];
 	unsigned long long rs_launches = 0; // histogram + pass kernels enqueued so far (ugrt_ctx_get_state "radix_launches")
 	bool rs_prehist = false;      // the first pass's histogram rows hold the counts of a producer whose sort has not run yet
 	int rs_atomic_rank = -1;      // k_rs_selftest: 1 = LDS add-with-return serves equal addresses in lane order on this device
@@ -212,6 +225,15 @@ int ugrt_prim_sort_pairs_rocprim(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const
 // ugrt_sort.hip
 int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
 			const u32 *n_dev = nullptr, bool prehist = false);
+// up to two independent lists in shared launches (ugrt_sort.hip)
+struct RsJob {
+	const u32 *kin, *vin;
+	u32 *kout, *vout;
+	size_t n;
+	int end_bit;
+	const u32 *n_dev;
+};
+int ugrt_sort_pairs_batch(ugrt_ctx *ctx, const RsJob *jobs, int njobs, bool prehist = false);
 int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,
 			   int end_bit);
 

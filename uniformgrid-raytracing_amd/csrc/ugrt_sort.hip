@@ -34,37 +34,57 @@
 #define RS_ITEMS_MAX 16 // pairs per thread: 16 (tiles of 8192 pairs) or 8 (4096: option "sort_items")
 #define RS_CHUNK 16 // tiles per chunk of the two-level offset computation
 
-// the sort's state (u32 words): histogram rows [pass][copy][digit], then per pass {ticket, finished workgroups}
-#define RS_HEAD_WORDS (RS_MAXPASS * RS_COPIES * RS_BINS + 2 * RS_MAXPASS + 56)
 
 typedef unsigned long long u64w; // look-back word: epoch << 32 | count
 
-// histogram of the first pass's digit (n_dev: the number of pairs when only the device knows it; n is then the
-// capacity the launch was sized for)
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u32 *__restrict__ keys, u32 n, u32 dmask, u32 *hist, const u32 *__restrict__ n_dev)
+// One launch may serve up to RS_MAXSEG independent sorts (segments): the light grid's and the uniform grid's references
+// depend on the geometry only, and their sorts share the launches of every pass level (ugrt_sort_pairs_batch) -- twice
+// the tiles in flight per launch hide the per-tile chain, and a frame has three launches less.
+#define RS_MAXSEG 2
+struct RsSeg {
+	const u32 *kin, *vin;
+	u32 *kout, *vout;
+	const u32 *n_dev;      // the pair count when only the device knows it (n is then the capacity the launch was sized for)
+	u32 *hist, *hist_next; // this pass's rows [copy][digit] / the rows of the pass that follows
+	u64w *look, *look2;    // [tile][digit] tile counts, [chunk][digit] chunk sums
+	u32 n, dmask, nmask;   // nmask: digit mask of the pass that follows (0: this is the segment's last pass)
+	u32 blocks;            // workgroups of this launch that belong to the segment
+};
+struct RsBatch {
+	RsSeg s[RS_MAXSEG];
+	u32 nseg;
+};
+
+// histogram of the first pass's digit
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(RsBatch b)
 {
-	if (n_dev)
-		n = *n_dev < n ? *n_dev : n;
+	const u32 si = b.nseg > 1u && blockIdx.x >= b.s[0].blocks ? 1u : 0u;
+	const RsSeg &g = b.s[si];
+	const u32 blk = blockIdx.x - (si ? b.s[0].blocks : 0u);
+	const u32 *__restrict__ keys = g.kin;
+	u32 n = g.n;
+	if (g.n_dev)
+		n = *g.n_dev < n ? *g.n_dev : n;
 	__shared__ u32 s_h[RS_BINS * RS_PRIV];
 	for (u32 i = threadIdx.x; i < RS_BINS * RS_PRIV; i += RS_THREADS)
 		s_h[i] = 0u;
 	__syncthreads();
 	// few workgroups: every one ends with up to 256 global adds
-	const u32 stride = gridDim.x * RS_THREADS;
-	for (u32 i0 = blockIdx.x * RS_THREADS + threadIdx.x; i0 < n; i0 += 4u * stride) {
+	const u32 stride = g.blocks * RS_THREADS;
+	for (u32 i0 = blk * RS_THREADS + threadIdx.x; i0 < n; i0 += 4u * stride) {
 		u32 k4[4];
 #pragma unroll
 		for (u32 u = 0; u < 4; u++)
 			k4[u] = i0 + u * stride < n ? keys[i0 + u * stride] : 0u;
 #pragma unroll
 		for (u32 u = 0; u < 4; u++)
-			d_rs_count(s_h, k4[u] & dmask, i0 + u * stride < n);
+			d_rs_count(s_h, k4[u] & g.dmask, i0 + u * stride < n);
 	}
 	__syncthreads();
 	if (threadIdx.x < RS_BINS) {
 		const u32 c = d_rs_count_sum(s_h, threadIdx.x);
 		if (c)
-			atomicAdd(&hist[(blockIdx.x % RS_COPIES) * RS_BINS + threadIdx.x], c);
+			atomicAdd(&g.hist[(blk % RS_COPIES) * RS_BINS + threadIdx.x], c);
 	}
 }
 
@@ -258,18 +278,11 @@ __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32
 	}
 }
 
-// hist: this pass's rows [copy][digit] (complete: the kernel before wrote them);  hist_next: the rows of the pass that
-// follows (nmask = its digit mask, 0 on the last pass);  look: [tile][digit] tile counts;  look2: [chunk][digit] chunk
-// sums;  ctl: {ticket, finished}
+// ctl: {ticket, finished workgroups} of the launch.  Tickets are dealt over the segments in turn (segment 0's tiles
+// first): inside a segment the tiles still come in ticket order, so a tile only ever waits for tiles that already run.
 template <int RS_ITEMS, bool ATOMIC>
-__global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(const u32 *__restrict__ kin, const u32 *__restrict__ vin,
-							 u32 *__restrict__ kout, u32 *__restrict__ vout, u32 n, u32 shift,
-							 u32 dmask, u32 *hist, u32 *hist_next, u32 nmask, u64w *look, u64w *look2,
-							 u32 chunk_cap, u32 *ctl, u32 epoch, const u32 *__restrict__ n_dev,
-							 u32 rows_to_clear)
+__global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(RsBatch b, u32 shift, u32 *ctl, u32 epoch)
 {
-	if (n_dev)
-		n = *n_dev < n ? *n_dev : n;
 	constexpr u32 RS_TILE = RS_THREADS * RS_ITEMS;
 	__shared__ u32 s_keys[RS_TILE], s_vals[RS_TILE];
 	__shared__ u32 s_cnt[RS_WAVES][RS_BINS]; // per wave: digit counters while ranking, then the first slot of the wave's pairs of the digit
@@ -281,29 +294,41 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 	const u32 t = threadIdx.x;
 	if (t == 0)
 		s_tile = atomicAdd(&ctl[0], 1u);
-	// this pass's digit totals are asked for before anything else (they are needed behind the ranks)
-	u32 gdigit_in = 0;
+	// this pass's digit totals (complete: the kernel before wrote the rows) are asked for before anything else, for both
+	// segments: which one this workgroup serves is known with the ticket
+	u32 gd0 = 0, gd1 = 0;
 	if (t < RS_BINS) {
 #pragma unroll
 		for (int c = 0; c < RS_COPIES; c++)
-			gdigit_in += hist[c * RS_BINS + t];
+			gd0 += b.s[0].hist[c * RS_BINS + t];
+		if (b.nseg > 1u) {
+#pragma unroll
+			for (int c = 0; c < RS_COPIES; c++)
+				gd1 += b.s[1].hist[c * RS_BINS + t];
+		}
 	}
-	if (nmask)
-		for (u32 i = t; i < RS_BINS * RS_PRIV; i += RS_THREADS)
-			s_next[i] = 0u;
+	for (u32 i = t; i < RS_BINS * RS_PRIV; i += RS_THREADS)
+		s_next[i] = 0u;
 	for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS)
 		(&s_cnt[0][0])[i] = 0;
 	__syncthreads();
-	const u32 tile = (u32)__builtin_amdgcn_readfirstlane((int)s_tile); // (uniform: row bases and loop bounds stay in scalar registers)
+	const u32 ticket = (u32)__builtin_amdgcn_readfirstlane((int)s_tile); // (uniform: row bases and loop bounds stay in scalar registers)
+	const u32 si = b.nseg > 1u && ticket >= b.s[0].blocks ? 1u : 0u;
+	const RsSeg &g = b.s[si];
+	const u32 tile = ticket - (si ? b.s[0].blocks : 0u);
+	const u32 gdigit_in = si ? gd1 : gd0;
+	u32 n = g.n;
+	if (g.n_dev)
+		n = *g.n_dev < n ? *g.n_dev : n;
 	const u32 base = tile * RS_TILE;
 	// (a launch sized by the capacity: a tile beyond the pairs holds nothing, and no tile waits for a later one)
 	if (base < n) {
 		if (n - base >= RS_TILE) // (no bounds checks in a full tile: all but the last)
-			d_rs_tile<RS_ITEMS, ATOMIC, true>(kin, vin, kout, vout, n, shift, dmask, gdigit_in, hist_next, nmask, look, look2, epoch,
-							  tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
+			d_rs_tile<RS_ITEMS, ATOMIC, true>(g.kin, g.vin, g.kout, g.vout, n, shift, g.dmask, gdigit_in, g.hist_next, g.nmask, g.look,
+							  g.look2, epoch, tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
 		else
-			d_rs_tile<RS_ITEMS, ATOMIC, false>(kin, vin, kout, vout, n, shift, dmask, gdigit_in, hist_next, nmask, look, look2, epoch,
-							   tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
+			d_rs_tile<RS_ITEMS, ATOMIC, false>(g.kin, g.vin, g.kout, g.vout, n, shift, g.dmask, gdigit_in, g.hist_next, g.nmask, g.look,
+							   g.look2, epoch, tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
 	}
 	// the last workgroup to finish leaves this pass's histogram rows, ticket and counter at zero for the next sort
 	// (every workgroup has read the rows by now: a workgroup counts itself in after its own reads)
@@ -312,8 +337,11 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 		s_last = atomicAdd(&ctl[1], 1u) == gridDim.x - 1u ? 1u : 0u;
 	__syncthreads();
 	if (s_last) {
-		for (u32 i = t; i < rows_to_clear * RS_COPIES * RS_BINS; i += RS_THREADS)
-			hist[i] = 0u;
+		for (u32 i = t; i < RS_COPIES * RS_BINS; i += RS_THREADS) {
+			b.s[0].hist[i] = 0u;
+			if (b.nseg > 1u)
+				b.s[1].hist[i] = 0u;
+		}
 		if (t == 0) {
 			ctl[0] = 0u;
 			ctl[1] = 0u;
@@ -363,27 +391,37 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_selftest(u32 *bad)
 		atomicAdd(bad, wrong);
 }
 
+// state: RS_MAXSEG heads (histogram rows [pass][copy][digit]), the launches' {ticket, finished} words per pass level,
+// then per segment the look-back words of the running pass (tile counts, chunk sums) for `tiles` tiles each
+static size_t rs_look_words64(u32 tiles)
+{
+	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
+	return (size_t)chunks * RS_CHUNK * RS_BINS + (size_t)chunks * RS_BINS;
+}
+#define RS_HIST_WORDS (RS_MAXPASS * RS_COPIES * RS_BINS)
+#define RS_HEADS_WORDS (RS_MAXSEG * RS_HIST_WORDS + 2 * RS_MAXPASS + 56)
+
 static int rs_state(ugrt_ctx *ctx, u32 tiles)
 {
-	// the head (histogram rows, tickets), then the look-back words of the running pass: tile counts, chunk sums
-	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
-	const size_t look_words64 = (size_t)chunks * RS_CHUNK * RS_BINS + (size_t)chunks * RS_BINS;
-	const size_t bytes = (size_t)RS_HEAD_WORDS * 4 + look_words64 * 8;
-	if (bytes <= ctx->rs_state.cap)
+	const size_t bytes = (size_t)RS_HEADS_WORDS * 4 + (size_t)RS_MAXSEG * rs_look_words64(tiles) * 8;
+	if (bytes <= ctx->rs_state.cap && tiles <= ctx->rs_tiles)
 		return UGRT_OK;
-	// growing: between two sorts the head is all zeros (every pass cleans up behind itself); only the first pass's rows
+	if (tiles < ctx->rs_tiles)
+		tiles = ctx->rs_tiles;
+	// growing: between two sorts the heads are all zeros (every pass cleans up behind itself); only the first pass's rows
 	// may hold what the producer of the coming sort's keys has counted
 	DevBuf old = ctx->rs_state;
 	ctx->rs_state = DevBuf();
-	int rc = ugrt_buf_reserve(ctx, ctx->rs_state, bytes);
+	int rc = ugrt_buf_reserve(ctx, ctx->rs_state, (size_t)RS_HEADS_WORDS * 4 + (size_t)RS_MAXSEG * rs_look_words64(tiles) * 8);
 	if (rc) {
 		ctx->rs_state = old;
 		return rc;
 	}
+	ctx->rs_tiles = tiles;
 	UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, ctx->rs_state.cap, ctx->stream));
 	if (ctx->rs_atomic_rank < 0) {
 		// once per context: may the passes rank by LDS atomics on this device?  (the look-back words serve as scratch)
-		u32 *bad = (u32 *)ctx->rs_state.p + RS_HEAD_WORDS, h_bad = 1;
+		u32 *bad = (u32 *)ctx->rs_state.p + RS_HEADS_WORDS, h_bad = 1;
 		hipLaunchKernelGGL(k_rs_selftest, dim3(4), dim3(RS_THREADS), 0, ctx->stream, bad);
 		UGRT_HIP(hipGetLastError());
 		UGRT_HIP(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -414,68 +452,110 @@ int ugrt_sort_first_digit(ugrt_ctx *ctx, RsFirst *out)
 	return UGRT_OK;
 }
 
-// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
-// (n_dev != nullptr: the pair count lives on the device and n is the capacity the launches are sized for;
-// prehist: the kernel that wrote the keys has counted their first digit, ugrt_sort_first_digit)
-int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
-			const u32 *n_dev, bool prehist)
+// Stable sorts of up to RS_MAXSEG independent lists of pairs on key bits [0, end_bit) in shared launches: one histogram
+// kernel, one kernel per pass level (a list with fewer passes drops out).  kin/vin are left untouched, the results are in
+// kout/vout.  n_dev != nullptr: the pair count lives on the device and n is the capacity the launches are sized for.
+// prehist (a single list only): the kernel that wrote the keys has counted their first digit (ugrt_sort_first_digit).
+int ugrt_sort_pairs_batch(ugrt_ctx *ctx, const RsJob *jobs, int njobs, bool prehist)
 {
-	if (ctx->rs_prehist && (!prehist || n == 0)) { // counts of a producer whose sort does not run: forget them
+	if (njobs < 1 || njobs > RS_MAXSEG)
+		return ugrt_fail(UGRT_EINVAL, "sort: %d lists in one batch (1..%d)", njobs, RS_MAXSEG);
+	size_t nmax = 0, nsum = 0;
+	for (int j = 0; j < njobs; j++) {
+		nmax = jobs[j].n > nmax ? jobs[j].n : nmax;
+		nsum += jobs[j].n;
+	}
+	if (ctx->rs_prehist && (!prehist || njobs != 1 || nsum == 0)) { // counts of a producer whose sort does not run: forget them
 		UGRT_HIP(hipMemsetAsync(ctx->rs_state.p, 0, (size_t)RS_COPIES * RS_BINS * 4, ctx->stream));
 		ctx->rs_prehist = false;
 	}
-	if (n == 0)
+	if (nsum == 0)
 		return UGRT_OK;
-	if (n > ((size_t)1 << 30))
-		return ugrt_fail(UGRT_EINVAL, "sort: %zu pairs exceed 2^30", n);
-	if (end_bit < 1)
-		end_bit = 1;
-	if (end_bit > 32)
-		end_bit = 32;
-	const int passes = (end_bit + 7) / 8;
+	if (nmax > ((size_t)1 << 30))
+		return ugrt_fail(UGRT_EINVAL, "sort: %zu pairs exceed 2^30", nmax);
 	// pairs per thread: tiles of 4096 pairs finish a pass of up to ~1 M pairs sooner, tiles of 8192 are faster from 1 M
 	// on (half the tickets and look-back rows; profiles/r04_sort_bench_*.json)
-	const int items = ctx->opt[UGRT_OPT_SORT_ITEMS] > 0 ? (ctx->opt[UGRT_OPT_SORT_ITEMS] == 8 ? 8 : 16) : (n <= (3u << 18) ? 8 : 16);
+	const int items = ctx->opt[UGRT_OPT_SORT_ITEMS] > 0 ? (ctx->opt[UGRT_OPT_SORT_ITEMS] == 8 ? 8 : 16) : (nmax <= (3u << 18) ? 8 : 16);
 	const u32 RS_TILE = (u32)(RS_THREADS * items);
-	const u32 tiles = (u32)((n + RS_TILE - 1) / RS_TILE);
 	hipStream_t st = ctx->stream;
 	int rc;
-	if ((rc = rs_state(ctx, tiles)))
+	if ((rc = rs_state(ctx, (u32)((nmax + RS_TILE - 1) / RS_TILE))))
 		return rc;
-	if (passes > 1) {
-		if ((rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[0], n * 4)) || (rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[1], n * 4)))
+	int end_bit[RS_MAXSEG], passes[RS_MAXSEG], maxpasses = 0;
+	u32 tiles[RS_MAXSEG];
+	for (int j = 0; j < njobs; j++) {
+		end_bit[j] = jobs[j].end_bit < 1 ? 1 : (jobs[j].end_bit > 32 ? 32 : jobs[j].end_bit);
+		passes[j] = jobs[j].n ? (end_bit[j] + 7) / 8 : 0;
+		maxpasses = passes[j] > maxpasses ? passes[j] : maxpasses;
+		tiles[j] = (u32)((jobs[j].n + RS_TILE - 1) / RS_TILE);
+		if (passes[j] > 1 && ((rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[j][0], jobs[j].n * 4)) ||
+				      (rc = ugrt_buf_reserve(ctx, ctx->rs_tmp[j][1], jobs[j].n * 4))))
 			return rc;
 	}
-	u32 *hist = (u32 *)ctx->rs_state.p, *ctl = hist + RS_MAXPASS * RS_COPIES * RS_BINS;
-	const u32 chunks = (tiles + RS_CHUNK - 1) / RS_CHUNK;
-	u64w *look = (u64w *)((u32 *)ctx->rs_state.p + RS_HEAD_WORDS);
-	u64w *look2 = look + (size_t)chunks * RS_CHUNK * RS_BINS;
-	auto bits_of_pass = [end_bit](int p) { return (u32)(end_bit - 8 * p) < 8u ? (u32)(end_bit - 8 * p) : 8u; };
-	if (prehist && ctx->rs_prehist) {
+	u32 *heads = (u32 *)ctx->rs_state.p, *ctl = heads + RS_MAXSEG * RS_HIST_WORDS;
+	u64w *look0 = (u64w *)(heads + RS_HEADS_WORDS);
+	const size_t look_stride = rs_look_words64(ctx->rs_tiles);
+	auto bits_of_pass = [&](int j, int p) { return (u32)(end_bit[j] - 8 * p) < 8u ? (u32)(end_bit[j] - 8 * p) : 8u; };
+	// the segments of a launch: the lists that still have a pass at level p, in job order
+	auto batch_of = [&](int p, const u32 *const *ki, const u32 *const *vi, u32 *const *ko, u32 *const *vo, const u32 *blocks, RsBatch *b) {
+		b->nseg = 0;
+		for (int j = 0; j < njobs; j++) {
+			if (passes[j] <= p)
+				continue;
+			RsSeg &g = b->s[b->nseg++];
+			g.kin = ki[j], g.vin = vi[j], g.kout = ko[j], g.vout = vo[j];
+			g.n_dev = jobs[j].n_dev;
+			g.hist = heads + (size_t)j * RS_HIST_WORDS + (size_t)p * RS_COPIES * RS_BINS;
+			g.hist_next = heads + (size_t)j * RS_HIST_WORDS + (size_t)(p + 1 < passes[j] ? p + 1 : p) * RS_COPIES * RS_BINS;
+			g.look = look0 + (size_t)j * look_stride;
+			g.look2 = g.look + (size_t)((ctx->rs_tiles + RS_CHUNK - 1) / RS_CHUNK) * RS_CHUNK * RS_BINS;
+			g.n = (u32)jobs[j].n;
+			g.dmask = (1u << bits_of_pass(j, p)) - 1u;
+			g.nmask = p + 1 < passes[j] ? (1u << bits_of_pass(j, p + 1)) - 1u : 0u;
+			g.blocks = blocks[j];
+		}
+		for (u32 k = b->nseg; k < RS_MAXSEG; k++)
+			b->s[k] = b->s[0];
+	};
+	const u32 *ki[RS_MAXSEG], *vi[RS_MAXSEG];
+	u32 *ko[RS_MAXSEG], *vo[RS_MAXSEG];
+	for (int j = 0; j < njobs; j++)
+		ki[j] = jobs[j].kin, vi[j] = jobs[j].vin, ko[j] = jobs[j].kout, vo[j] = jobs[j].vout;
+	if (prehist && njobs == 1 && ctx->rs_prehist) {
 		ctx->rs_prehist = false; // (the first pass reads the rows and its last workgroup clears them)
 	} else {
-		u32 hblocks = (u32)((n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
-		hblocks = hblocks > 256u ? 256u : (hblocks ? hblocks : 1u);
-		hipLaunchKernelGGL(k_rs_hist, dim3(hblocks), dim3(RS_THREADS), 0, st, kin, (u32)n, (1u << bits_of_pass(0)) - 1u, hist, n_dev);
+		u32 hblocks[RS_MAXSEG], total = 0;
+		for (int j = 0; j < njobs; j++) {
+			u32 h = (u32)((jobs[j].n + RS_THREADS * 8 - 1) / (RS_THREADS * 8));
+			hblocks[j] = passes[j] ? (h > 256u ? 256u : (h ? h : 1u)) : 0u;
+			total += hblocks[j];
+		}
+		RsBatch b;
+		batch_of(0, ki, vi, ko, vo, hblocks, &b);
+		hipLaunchKernelGGL(k_rs_hist, dim3(total), dim3(RS_THREADS), 0, st, b);
 		UGRT_HIP(hipGetLastError());
 		ctx->rs_launches++;
 	}
 	// ranks by LDS atomics where the device serves them in lane order (checked once per context), unless "sort_rank" is 0
 	const bool atomic_rank = ctx->rs_atomic_rank == 1 && ctx->opt[UGRT_OPT_SORT_RANK] != 0;
-	const u32 *ki = kin, *vi = vin;
-	for (int p = 0; p < passes; p++) {
-		// the buffers alternate so that the last pass writes the caller's output
-		const bool to_out = ((passes - 1 - p) & 1) == 0;
-		u32 *ko = to_out ? kout : (u32 *)ctx->rs_tmp[0].p, *vo = to_out ? vout : (u32 *)ctx->rs_tmp[1].p;
-		const u32 bits = bits_of_pass(p), nmask = p + 1 < passes ? (1u << bits_of_pass(p + 1)) - 1u : 0u;
+	for (int p = 0; p < maxpasses; p++) {
+		u32 total = 0, blocks[RS_MAXSEG];
+		for (int j = 0; j < njobs; j++) {
+			// the buffers alternate so that a list's last pass writes the caller's output
+			const bool to_out = ((passes[j] - 1 - p) & 1) == 0;
+			ko[j] = to_out ? jobs[j].kout : (u32 *)ctx->rs_tmp[j][0].p;
+			vo[j] = to_out ? jobs[j].vout : (u32 *)ctx->rs_tmp[j][1].p;
+			blocks[j] = passes[j] > p ? tiles[j] : 0u;
+			total += blocks[j];
+		}
+		RsBatch b;
+		batch_of(p, ki, vi, ko, vo, blocks, &b);
 		if (++ctx->rs_epoch == 0u) { // (2^32 passes later: old tags could be taken for new ones)
-			UGRT_HIP(hipMemsetAsync(look, 0, ctx->rs_state.cap - (size_t)RS_HEAD_WORDS * 4, st));
+			UGRT_HIP(hipMemsetAsync(look0, 0, ctx->rs_state.cap - (size_t)RS_HEADS_WORDS * 4, st));
 			ctx->rs_epoch = 1;
 		}
-#define RS_LAUNCH(ITEMS, ATOMIC)                                                                                                     \
-	hipLaunchKernelGGL((k_rs_pass<ITEMS, ATOMIC>), dim3(tiles), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, (u32)n, (u32)(8 * p),     \
-			   (1u << bits) - 1u, hist + (size_t)p * RS_COPIES * RS_BINS, hist + (size_t)(p + 1 < passes ? p + 1 : p) * RS_COPIES * RS_BINS, \
-			   nmask, look, look2, chunks, ctl + 2 * p, ctx->rs_epoch, n_dev, 1u)
+#define RS_LAUNCH(ITEMS, ATOMIC) \
+	hipLaunchKernelGGL((k_rs_pass<ITEMS, ATOMIC>), dim3(total), dim3(RS_THREADS), 0, st, b, (u32)(8 * p), ctl + 2 * p, ctx->rs_epoch)
 		if (items == 8) {
 			if (atomic_rank)
 				RS_LAUNCH(8, true);
@@ -490,8 +570,17 @@ int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin
 #undef RS_LAUNCH
 		ctx->rs_launches++;
 		UGRT_HIP(hipGetLastError());
-		ki = ko;
-		vi = vo;
+		for (int j = 0; j < njobs; j++)
+			if (passes[j] > p)
+				ki[j] = ko[j], vi[j] = vo[j];
 	}
 	return UGRT_OK;
+}
+
+// stable sort of n pairs on key bits [0, end_bit); kin/vin are left untouched, the result is in kout/vout
+int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
+			const u32 *n_dev, bool prehist)
+{
+	const RsJob job = { kin, vin, kout, vout, n, end_bit, n_dev };
+	return ugrt_sort_pairs_batch(ctx, &job, 1, prehist);
 }

@@ -101,6 +101,14 @@ class Context:
     def grid_build_uniform(self, d_faces, d_verts, num_faces, bbmin, bbmax):
         check(lib.ugrt_grid_build_uniform(self._h, _ptr(d_faces), _ptr(d_verts), num_faces, _f3(bbmin), _f3(bbmax)))
 
+    def grid_build_batch_begin(self):
+        """The grid builds that follow (at most two, asynchronous form) stop in front of their sorts ..."""
+        check(lib.ugrt_grid_build_batch_begin(self._h))
+
+    def grid_build_batch_end(self):
+        """... and are sorted in shared launches and completed here; the grids must not be used before."""
+        check(lib.ugrt_grid_build_batch_end(self._h))
+
     def grid_info(self, which):
         gi = GridInfo()
         check(lib.ugrt_grid_get_info(self._h, which, C.byref(gi)))

@@ -44,7 +44,7 @@ def make_camera(params, fovy, aspect):
 
 class Renderer:
     def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False,
-                 shards=None, helper_thread=True, aux_stream=None):
+                 shards=None, helper_thread=True, aux_stream=None, batch_builds=True):
         """overlap=True: the light grid and the uniform grid (which do not depend on the camera pass) are built
         by a second context on a second HIP stream while the main stream builds the perspective grid and
         traces the primary rays; streams are joined with events before the grids are consumed.  Same results.
@@ -58,6 +58,8 @@ class Renderer:
         # per rank, exchanged and merged; one-stream frames only
         self.shards = shards
         assert not (overlap and shards is not None), "sharded builds run in the one-stream frame"
+        # (two-stream frame from one host thread: the light and the uniform build share their sorts' launches)
+        self.batch_builds = batch_builds
         if overlap:
             from .device import Context
 
@@ -352,12 +354,21 @@ class Renderer:
             self._ensure_reflect_buffers()
         ev_primary, ev_light_grid = t.cuda.Event(), t.cuda.Event()
         side.wait_stream(main)  # the geometry of this frame is final on the main stream
+        # the light grid and the uniform grid depend on the geometry only: their reference lists are sorted in shared
+        # launches (one histogram kernel and one kernel per pass level for both: ugrt_grid_build_batch_begin / _end)
+        batch = shadows and reflect and self.batch_builds
+        if batch:
+            aux.grid_build_batch_begin()
         if shadows:
             aux.upload_camera(lcam.camcoords)
             aux.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
-            ev_light_grid.record(side)
+            if not batch:
+                ev_light_grid.record(side)
         if reflect:
             aux.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
+        if batch:
+            aux.grid_build_batch_end()
+            ev_light_grid.record(side)
         ctx.set_light_position(setup.shading_light)
         cam = make_camera(setup.camera, setup.fovy, self.aspect)
         self._upload_cam_pos(cam.worldori)

@@ -332,6 +332,10 @@ def main():
                          "(hall 1024x1024 primary + shadow = configs[1], the 3840x2160 frame on this one GPU = configs[3]'s "
                          "per-GPU ceiling, the animated rebuild = configs[4]; ~10 verified steps each, reported under "
                          "other_configs; the profile passes skip them so that their kernel averages are the headline's)")
+    ap.add_argument("--batch-builds", dest="batch_builds", action="store_true", default=False,
+                    help="the light grid and the uniform grid are built as one batch whose sorts share their launches "
+                         "(ugrt_grid_build_batch_begin / _end: three radix launches less per frame; measured 2 %% slower with "
+                         "four frames in flight, profiles/r04_batched_builds.txt; default: one after the other)")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
@@ -421,6 +425,7 @@ def main():
                 rr = ugrt.Renderer(cx, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
                                    overlap=not args.no_overlap and shards is None, shards=shards,
                                    helper_thread=args.waiting_builds, aux_stream=made.get(("side", i)))
+            rr.batch_builds = args.batch_builds
             if stream is not None:
                 rr._stream = stream
             # the bounce's persistent waves: with several frames in flight every ray group gets a wave of its own (the

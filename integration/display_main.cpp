@@ -177,7 +177,8 @@ void display() // main.cu:59-302
 		HIP_CHECK(hipEventRecord(ev_geometry, g_main));
 		HIP_CHECK(hipStreamWaitEvent(g_side, ev_geometry, 0));
 		UGRT_CHECK(ugrt_upload_camera(g_aux, light_cam.camcoords));
-		// (with the bounce both grids are built in one batch: their reference lists are sorted in shared launches)
+		// (with the bounce both grids are built in one batch: their reference lists are sorted in shared launches.  Three
+		// launches less; beside other frames in flight it measured 2 % slower, so the Python harness keeps it off)
 		if (P.reflect)
 			UGRT_CHECK(ugrt_grid_build_batch_begin(g_aux));
 		UGRT_CHECK(ugrt_grid_build_spherical(g_aux, model->d_facelist, model->d_vertexlist, model->num_faces, (float)M_PI,

@@ -44,7 +44,7 @@ def make_camera(params, fovy, aspect):
 
 class Renderer:
     def __init__(self, ctx, verts, faces, matidx, mat_list, reflect=None, reflect_eps=1e-3, overlap=False,
-                 shards=None, helper_thread=True, aux_stream=None, batch_builds=True):
+                 shards=None, helper_thread=True, aux_stream=None, batch_builds=False):
         """overlap=True: the light grid and the uniform grid (which do not depend on the camera pass) are built
         by a second context on a second HIP stream while the main stream builds the perspective grid and
         traces the primary rays; streams are joined with events before the grids are consumed.  Same results.
@@ -58,7 +58,9 @@ class Renderer:
         # per rank, exchanged and merged; one-stream frames only
         self.shards = shards
         assert not (overlap and shards is not None), "sharded builds run in the one-stream frame"
-        # (two-stream frame from one host thread: the light and the uniform build share their sorts' launches)
+        # (two-stream frame from one host thread: the light and the uniform build may share their sorts' launches --
+        # three launches less per frame, measured 2 % SLOWER with four frames in flight and equal with one:
+        # profiles/r04_batched_builds.txt -- so it is off unless asked for)
         self.batch_builds = batch_builds
         if overlap:
             from .device import Context

@@ -350,14 +350,14 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 }
 
 // Does an LDS add-with-return serve the lanes of one instruction that hit the same word in lane order?  512 threads rank
-// 64 rounds of pseudo-random digits (1 to 256 distinct ones per round, so every conflict degree occurs) both ways;
+// 32 rounds of pseudo-random digits (1 to 256 distinct ones per round, so every conflict degree occurs) both ways;
 // bad[0] counts the ranks that differ.
 __global__ __launch_bounds__(RS_THREADS) void k_rs_selftest(u32 *bad)
 {
 	__shared__ u32 s_a[RS_WAVES][RS_BINS], s_b[RS_WAVES][RS_BINS];
 	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
 	u32 wrong = 0;
-	for (u32 round = 0; round < 64u; round++) {
+	for (u32 round = 0; round < 32u; round++) {
 		for (u32 i = t; i < RS_WAVES * RS_BINS; i += RS_THREADS) {
 			(&s_a[0][0])[i] = 0;
 			(&s_b[0][0])[i] = 0;

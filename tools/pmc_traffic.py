@@ -51,7 +51,7 @@ def main():
     write = counters(one("write/*counter_collection.csv"))
     timed = [k for k in fetch if k.startswith("k_trace_primary<") and not k.endswith(", true>")]
     frames = sum(len(fetch[k]["FETCH_SIZE"]) for k in timed) or 1
-    rows, per_launch, per_frame = [], {}, {}
+    rows, per_launch, per_frame, most = [], {}, {}, {}
     for k in fetch:
         if not k.startswith("k_"):
             continue
@@ -64,7 +64,11 @@ def main():
         if ("<true, " in k and base in ("k_trace_dda_beam", "k_trace_dda_ray", "k_trace_dda_walk")) or \
                 (k.endswith(", true>") and base == "k_trace_primary"):
             continue  # the counting variants (k_trace_dda_*<COUNT, REC>, k_trace_primary<REC, COUNT>) run once, outside the timed frames
-        per_launch[base] = b
+        # (several instantiations of a kernel may run: the one launched most is the timed configuration's -- the bounce's
+        # lean form with frames in flight, its split-walk form in the one-frame leg)
+        if len(f) > most.get(base, 0):
+            most[base] = len(f)
+            per_launch[base] = b
         per_frame[base] = per_frame.get(base, 0) + int((2.0 * sum(f) + sum(w)) * 1024.0 / frames)
     per_launch["k_trace_dda"] = per_launch.get("k_trace_dda_walk", per_launch.get("k_trace_dda_beam", per_launch.get("k_trace_dda_ray", 0)))
     rows.sort(key=lambda r: -r["hbm_bytes_corrected"] * r["dispatches"])

@@ -193,9 +193,9 @@ int ugrt_ctx_create(ugrt_ctx **out, int device, const ugrt_config *cfg);
 int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
 /* launch-shape options of this context; none changes a result; value < 0 restores the default.  Keys:
  * "dda_kernel" 0 = window kernel (occupancy bitmap, jobs per occupied cell, (survivor, ray) pair rounds),
- * 1 = per-ray kernel of round 1, 2 = beam kernel of round 2; "dda_rays_per_wave" 1..64 (0 = default: 32, beam
- * kernel 64); "dda_cull_min" / "dda_cull_work": a job's list is culled against its ray bundle first from this
- * many triangles / (triangles x rays) on; "dda_coop" (kernels 1 and 2) list length from which a lone ray's cell is
+ * 1 = per-ray kernel of round 1 (kept as the cross-check); "dda_rays_per_wave" 1..64 (0 = default: 32);
+ * "dda_cull_min" / "dda_cull_work": a job's list is culled against its ray bundle first from this
+ * many triangles / (triangles x rays) on; "dda_coop" (kernel 1) list length from which a lone ray's cell is
  * tested by the whole wave; "dda_sort" 1 = the bounce's ray list sorted by (entry cell, octant) instead of tile
  * order; "dda_split" (window kernel) 1 = the ray groups that were long in the context's last bounce are cut into
  * segments of their walk that run on different waves and are merged per ray (default; the history is kept per pixel,

@@ -203,7 +203,7 @@ def test_reflection_bounce(ugrt, O, torch, name, cam, W, H):
                                          ("cornell", 128, 128, (33, 17, 5)), ("cornell", 96, 64, (3, 1000, 2)),
                                          ("cornell", 72, 40, (8, 8, 8))])  # (the last: a band that ends inside a 512-pixel span of the ray list)
 def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
-    """The three bounce kernels (0 window kernel, 1 per-ray, 2 beam kernel of round 2) at every launch shape, with
+    """The two bounce kernels (0 window kernel, 1 per-ray kernel of round 1) at every launch shape, with
     and without the (entry cell, octant) ray sort: hit ids equal, t bit-equal to the oracle; the counting variants
     report the oracle's work counts (tests, cells, rays of the algorithmic-byte formula)."""
     s = dict(scene(ugrt, name))
@@ -222,7 +222,7 @@ def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
               dict(dda_kernel=0, dda_cull_min=1, dda_cull_work=1), dict(dda_kernel=0, dda_cull_min=1 << 30),
               dict(dda_kernel=0, dda_cull_work=64), dict(dda_kernel=0, dda_sort=1),
               dict(dda_kernel=0, dda_sort=1, dda_rays_per_wave=24), dict(dda_kernel=0, dda_blocks=7),
-              dict(dda_kernel=1), dict(dda_kernel=2), dict(dda_kernel=2, dda_sort=1)]
+              dict(dda_kernel=1), dict(dda_kernel=1, dda_sort=1)]
     # split walks (the long groups of the launch before cut into segments; dda_split >= 2: every group): launches in a
     # row, so that each cuts by the history the one before it left
     shapes += [dict(dda_kernel=0, dda_split=1, dda_split_load=50)] * 3 + [dict(dda_kernel=0, dda_split=k) for k in (2, 3, 4, 4)]
@@ -242,7 +242,7 @@ def test_bounce_kernels_agree(ugrt, O, torch, name, W, H, ud):
     cr.display(setup, shadows=False, reflect=True)
     cctx.synchronize()
     cv, cs, co, _ = cctx.grid_ptrs(ugrt.GRID_UNIFORM)
-    for k in (0, 1, 2):
+    for k in (0, 1):
         cctx.set_option("dda_kernel", k)
         cr.hit_t.fill_(7.0)
         cctx.trace_dda(cv, cs, co, cr.d_verts, cr.d_faces, cr.rays, cr.active, cr.hit_t, cr.hit_id)
@@ -298,7 +298,7 @@ def test_bounce_kernels_on_synthetic_rays(ugrt, O, torch, name, ud, seed):
     r.active.copy_(torch.from_numpy(active).to(r.active.device))
     uvalue, uspan, uoffset, _ = ctx.grid_ptrs(ugrt.GRID_UNIFORM)
     for opts in (dict(dda_kernel=0), dict(dda_kernel=0, dda_rays_per_wave=64), dict(dda_kernel=0, dda_cull_work=1, dda_cull_min=1),
-                 dict(dda_kernel=0, dda_sort=1), dict(dda_kernel=1), dict(dda_kernel=2)):
+                 dict(dda_kernel=0, dda_sort=1), dict(dda_kernel=1)):
         for k in ("dda_kernel", "dda_rays_per_wave", "dda_cull_min", "dda_cull_work", "dda_sort"):
             ctx.set_option(k, opts.get(k, -1))
         r.hit_t.fill_(7.0)
@@ -342,7 +342,7 @@ def test_bounce_kernels_on_synthetic_rays(ugrt, O, torch, name, ud, seed):
     cr.rays.copy_(r.rays)
     cr.active.copy_(r.active)
     cv, csn, co, _ = cctx.grid_ptrs(ugrt.GRID_UNIFORM)
-    for k in (0, 2):
+    for k in (0, 1):
         cctx.set_option("dda_kernel", k)
         cctx.trace_dda(cv, csn, co, cr.d_verts, cr.d_faces, cr.rays, cr.active, cr.hit_t, cr.hit_id)
         st = cctx.stats()

@@ -1,6 +1,6 @@
 """A few launches of the DDA alone on the bench workload (for rocprofv3 --pmc / --kernel-trace).
 
-    python tools/dda_only.py KERNEL RPW [launches [dda_split]]      KERNEL 0 = window, 1 = per-ray, 2 = beam
+    python tools/dda_only.py KERNEL RPW [launches [dda_split]]      KERNEL 0 = window, 1 = per-ray
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

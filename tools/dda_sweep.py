@@ -1,5 +1,5 @@
-"""DDA kernels on the bench workload, alone on the GPU: beam kernel against the per-ray kernel of round 1
-(identical results checked), launch-shape sweep, and the beam kernel's work-sharing counters.
+"""DDA kernels on the bench workload, alone on the GPU: the window kernel against the per-ray kernel of round 1
+(identical results checked), launch-shape sweep, and the window kernel's work-sharing counters.
 
     python tools/dda_sweep.py [--quick] [--out FILE.json]
 """
@@ -47,10 +47,10 @@ ms_ray = run(ctx, r)
 ref_t, ref_id = r.hit_t.clone(), r.hit_id.clone()
 print("per-ray kernel, 32 rays per wave: %.3f ms" % ms_ray, flush=True)
 res["per_ray_rpw32_ms"] = ms_ray
-for kernel in (2, 0):  # 2 = beam kernel of round 2, 0 = window kernel
+for kernel in (0,):  # the window kernel (round 2's beam kernel went in round 4)
     for sort in (0, 1):
         for rpw in ((64,) if (quick or sort) else (16, 32, 64)):
-            for cull_min in ((8,) if (quick or kernel == 2 or sort) else (8, 4, 16, 1 << 30)):
+            for cull_min in ((8,) if (quick or sort) else (8, 4, 16, 1 << 30)):
                 ctx.set_option("dda_kernel", kernel)
                 ctx.set_option("dda_sort", sort)
                 ctx.set_option("dda_rays_per_wave", rpw)

@@ -61,7 +61,7 @@ def main():
         base = k.split("<")[0]
         rows.append({"kernel": k, "dispatches": len(f), "dispatches_per_frame": round(len(f) / frames, 2),
                      "FETCH_SIZE_KB_avg": round(favg, 1), "WRITE_SIZE_KB_avg": round(wavg, 1), "hbm_bytes_corrected": b})
-        if ("<true, " in k and base in ("k_trace_dda_beam", "k_trace_dda_ray", "k_trace_dda_walk")) or \
+        if ("<true, " in k and base in ("k_trace_dda_ray", "k_trace_dda_walk")) or \
                 (k.endswith(", true>") and base == "k_trace_primary"):
             continue  # the counting variants (k_trace_dda_*<COUNT, REC>, k_trace_primary<REC, COUNT>) run once, outside the timed frames
         # (several instantiations of a kernel may run: the one launched most is the timed configuration's -- the bounce's
@@ -70,7 +70,7 @@ def main():
             most[base] = len(f)
             per_launch[base] = b
         per_frame[base] = per_frame.get(base, 0) + int((2.0 * sum(f) + sum(w)) * 1024.0 / frames)
-    per_launch["k_trace_dda"] = per_launch.get("k_trace_dda_walk", per_launch.get("k_trace_dda_beam", per_launch.get("k_trace_dda_ray", 0)))
+    per_launch["k_trace_dda"] = per_launch.get("k_trace_dda_walk", per_launch.get("k_trace_dda_ray", 0))
     rows.sort(key=lambda r: -r["hbm_bytes_corrected"] * r["dispatches"])
     import bench
 

@@ -191,7 +191,7 @@ static const struct {
 	const char *key;
 	int lo, hi;
 } k_opt[UGRT_OPT_COUNT] = {
-	{ "dda_rays_per_wave", 0, 64 }, { "dda_coop", 1, 1 << 30 },     { "dda_kernel", 0, 2 },
+	{ "dda_rays_per_wave", 0, 64 }, { "dda_coop", 1, 1 << 30 },     { "dda_kernel", 0, 1 },
 	{ "dda_cull_min", 1, 1 << 30 }, { "dda_blocks", 1, 1 << 20 },
 	{ "primary_seg", 64, 1 << 20 }, { "shadow_beam", 64, 8192 },
 	{ "shadow_xseg", 64, 1 << 20 }, { "shadow_sizebits", 0, 8 },    { "shadow_itemsort", 0, 1 },

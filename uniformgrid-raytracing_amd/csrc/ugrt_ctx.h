@@ -23,7 +23,7 @@ struct CamBlock {
 enum {
 	UGRT_OPT_DDA_RPW = 0,      // "dda_rays_per_wave"
 	UGRT_OPT_DDA_COOP,         // "dda_coop": list length from which a lone ray's cell is tested by the whole wave
-	UGRT_OPT_DDA_KERNEL,       // "dda_kernel": 0 = window kernel, 1 = per-ray kernel of round 1, 2 = beam kernel of round 2
+	UGRT_OPT_DDA_KERNEL,       // "dda_kernel": 0 = window kernel, 1 = per-ray kernel of round 1 (the cross-check)
 	UGRT_OPT_DDA_CULL_MIN,     // "dda_cull_min": list length from which a shared cell is culled before the exact tests
 	UGRT_OPT_DDA_BLOCKS,       // "dda_blocks": upper bound of the persistent waves of ugrt_trace_dda
 	UGRT_OPT_PRIMARY_SEG,      // "primary_seg"

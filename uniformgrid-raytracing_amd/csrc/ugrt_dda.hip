@@ -4,14 +4,12 @@
 // (Amanatides & Woo), test every triangle of a cell's list in ascending id with the reference's
 // Moller-Trumbore (signed t, 0 < t < best), stop at the first cell whose best hit lies before the cell's
 // exit.  Two kernels compute it:
-//   k_trace_dda_beam (default) -- the rays of a wave are neighbours on the screen (the list is built in 8x8
-//     tile order), so they walk the same cells at the same time.  The walk stays per lane and exact, but the
-//     work inside a cell is shared: the lanes that stand in the same cell form a group, the cell's triangles
-//     are loaded ONCE per group (lane = triangle), culled against the group's ray bundle with the interval
-//     test of the primary/shadow tracers extended to rays with different origins, and only the survivors
-//     are tested by the group's rays (lane = ray, triangle broadcast from registers).
+//   k_trace_dda_walk (ugrt_dda_walk.hip, the default) -- the window kernel of round 3;
 //   k_trace_dda_ray (option "dda_kernel" = 1) -- round 1's kernel: every ray walks and tests alone, long
-//     lists are tested by the whole wave for one owner at a time.  Kept as the before/after reference.
+//     lists are tested by the whole wave for one owner at a time.  Kept as the plain GPU form of the specification
+//     that the window kernel is compared with (tests/test_gpu_parity.py::test_bounce_kernels_agree).
+// (Round 2's beam kernel, which shared the work inside a cell among the rays that stood in it, was the window kernel's
+// predecessor; it went in round 4, when nothing used it any more.)
 #include "ugrt_dda.h"
 
 
@@ -321,391 +319,9 @@ __global__ __launch_bounds__(64) void k_trace_dda_ray(DGrid g, const u32 *__rest
 }
 
 
-// ---------------------------------------------------------------------------
-// beam kernel
-// ---------------------------------------------------------------------------
-
-#define BEAM_AHEAD 8 // cells planned (and their headers fetched) per round trip of the beam kernel
-#define DDA_MAXLAG 7 // a ray may wait this many steps for the rays behind it (phase alignment, below)
-
-// beam-kernel statistics (COUNT variant only): counters[3..]
-enum { DS_ITER = 3, DS_GROUPS, DS_GROUP_LANES, DS_CULL_BATCHES, DS_CULL_TESTS, DS_EXACT_ROUNDS, DS_EXACT_LANES, DS_SOLO_ROUNDS,
-       DS_HIST_CYCLES /* 16 buckets: waves by log2(cycles / 4096) */, DS_SUM_CYCLES = DS_HIST_CYCLES + 16, DS_MAX_CYCLES,
-       DS_PHASE /* 8: cycles in plan+headers, job list, operand arrival, box, cull, exact rounds, lone rays, rest */, DS_PHASE_HEAVY = DS_PHASE + 8 /* the same for waves of >= 2^20 cycles, then their count and their rounds, groups, iterations */, DS_END = DS_PHASE_HEAVY + 12 };
-
-// phase stamps of the COUNT variant: the cycles since the previous stamp go to phase PH
-#define DDA_STAMP(PH)                                              \
-	do {                                                       \
-		if (COUNT) {                                       \
-			const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-			ph[PH] += now_ - tstamp;                   \
-			tstamp = now_;                             \
-		}                                                  \
-	} while (0)
-
-template <bool COUNT, bool REC>
-__global__ __launch_bounds__(64, 3) void k_trace_dda_beam(DGrid g, const u32 *__restrict__ value_list,
-							const u32 *__restrict__ span, const u32 *__restrict__ offset,
-							const float *__restrict__ verts, const int *__restrict__ tris,
-							const float4 *__restrict__ rec, const float *__restrict__ rays,
-							const u32 *__restrict__ list, const u32 *__restrict__ count_p,
-							float *__restrict__ hit_t, int *__restrict__ hit_id,
-							unsigned long long *__restrict__ counters, u32 DDA_RPW, u32 DDA_COOP,
-							u32 CULL_MIN, u32 *__restrict__ ticket)
-{
-	__shared__ u32 s_cell[BEAM_AHEAD][64], s_sp[BEAM_AHEAD][64], s_off[BEAM_AHEAD][64], s_flag[BEAM_AHEAD][64];
-	__shared__ float s_tin[BEAM_AHEAD][64], s_tnext[BEAM_AHEAD][64];
-	__shared__ u32 s_jend[BEAM_AHEAD];
-	__shared__ unsigned short s_job[BEAM_AHEAD * 64]; // step << 8 | a lane that stands in the job's cell
-	const int lane = threadIdx.x;
-	const u32 count = *count_p;
-	// The first group of a wave is its block index; further groups are drawn from a ticket, so a wave that is
-	// done takes the next group whatever the others do.  (No ticket for the first group: thousands of waves
-	// that start together would queue up on that one address, ~12 ns each.)
-	for (u32 grp = blockIdx.x; (unsigned long long)grp * DDA_RPW < count;) {
-		const unsigned long long clk0 = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
-		unsigned long long tstamp = clk0, ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-		const u32 slot = grp * DDA_RPW + (u32)lane;
-		bool inb = (u32)lane < DDA_RPW && slot < count;
-		const int p = inb ? (int)list[slot] : 0;
-		inb = inb && p != -1; // (padding: k_dda_prepare)
-		float res_t = -1.0f;
-		int res_id = -2;
-		u32 n_cells = 0, n_tests = 0;
-		u32 st_iter = 0, st_groups = 0, st_glanes = 0, st_cb = 0, st_ct = 0, st_er = 0, st_el = 0, st_solo = 0;
-		float o[3] = { 0, 0, 0 }, d[3] = { 0, 0, 0 }, tmax[3] = { 0, 0, 0 }, tdelta[3] = { 0, 0, 0 };
-		int c[3] = { 0, 0, 0 }, step[3] = { 0, 0, 0 };
-		float best_t = 3.0e38f, tcur = 0.0f;
-		int best_id = -2;
-		bool walking = false;
-		// set-up: exactly the arithmetic of the per-ray kernel and of the specification
-		if (inb) {
-			float tenter = 0.0f, texit = 3.0e38f;
-#pragma unroll
-			for (int k = 0; k < 3; k++) {
-				o[k] = rays[p * 6 + k];
-				d[k] = rays[p * 6 + 3 + k];
-			}
-#pragma unroll
-			for (int k = 0; k < 3; k++) {
-				float lo = g.lo[k], hi = g.lo[k] + g.cs[k] * (float)g.dims[k];
-				if (d[k] != 0.0f) {
-					float inv = 1.0f / d[k];
-					float t0 = (lo - o[k]) * inv, t1 = (hi - o[k]) * inv;
-					if (t0 > t1) {
-						float s = t0;
-						t0 = t1;
-						t1 = s;
-					}
-					if (t0 > tenter)
-						tenter = t0;
-					if (t1 < texit)
-						texit = t1;
-				} else if (o[k] < lo || o[k] > hi) {
-					texit = -1.0f;
-				}
-			}
-			if (tenter <= texit) {
-				walking = true;
-				tcur = tenter;
-#pragma unroll
-				for (int k = 0; k < 3; k++) {
-					float pe = o[k] + tenter * d[k];
-					c[k] = d_dcell(g, k, pe);
-					if (d[k] > 0.0f) {
-						step[k] = 1;
-						tmax[k] = ((g.lo[k] + (float)(c[k] + 1) * g.cs[k]) - o[k]) / d[k];
-						tdelta[k] = g.cs[k] / d[k];
-					} else if (d[k] < 0.0f) {
-						step[k] = -1;
-						tmax[k] = ((g.lo[k] + (float)c[k] * g.cs[k]) - o[k]) / d[k];
-						tdelta[k] = -g.cs[k] / d[k];
-					} else {
-						step[k] = 0;
-						tmax[k] = 3.0e38f;
-						tdelta[k] = 3.0e38f;
-					}
-				}
-			}
-		}
-		// Phase alignment.  Every step moves a ray to a neighbour cell along its own direction signs, so
-		// w = sx*cx + sy*cy + sz*cz grows by exactly one per step, and two rays of one octant can only meet
-		// in a cell at equal w.  Rays that start up to DDA_MAXLAG steps ahead of the rearmost ray of their
-		// cluster therefore wait that many steps: from then on neighbours stand in the same cell in the same
-		// iteration, which is what the sharing below needs.  (Waiting changes no result.)
-		int lag = 0;
-		{
-			const int w0 = step[0] * c[0] + step[1] * c[1] + step[2] * c[2];
-			bool open = walking;
-			for (int pass = 0; pass < 4 && __ballot(open) != 0ull; pass++) {
-				const int wmin = d_wave_imin(open ? w0 : 0x7FFFFFFF);
-				if (open && w0 - wmin <= DDA_MAXLAG) {
-					lag = w0 - wmin;
-					open = false;
-				}
-			}
-		}
-		// every step leaves a cell for good, so dims[0]+dims[1]+dims[2] bounds the walk
-		int guard = g.dims[0] + g.dims[1] + g.dims[2] + 3;
-		u32 njobs = 0;
-		while (__ballot(walking) != 0ull) {
-			if (COUNT)
-				st_iter++;
-			DDA_STAMP(7);
-			// 1. plan the next BEAM_AHEAD cells and fetch their headers together (one round trip per BEAM_AHEAD
-			//    steps).  The plan lives in LDS, every lane its own column.
-			{
-				u32 pcell[BEAM_AHEAD], pflag[BEAM_AHEAD];
-				bool planning = walking;
-#pragma unroll
-				for (int q = 0; q < BEAM_AHEAD; q++) {
-					pflag[q] = 0u;
-					pcell[q] = 0u;
-					s_tin[q][lane] = tcur;
-					if (planning && lag > 0) {
-						lag--;
-					} else if (planning) {
-						pflag[q] = 1u;
-						pcell[q] = (u32)((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]);
-						int ax = (tmax[0] < tmax[1]) ? ((tmax[0] < tmax[2]) ? 0 : 2) : ((tmax[1] < tmax[2]) ? 1 : 2);
-						tcur = ax == 0 ? tmax[0] : (ax == 1 ? tmax[1] : tmax[2]);
-						bool outside;
-						if (ax == 0) {
-							c[0] += step[0];
-							outside = step[0] == 0 || c[0] < 0 || c[0] >= g.dims[0];
-							tmax[0] += tdelta[0];
-						} else if (ax == 1) {
-							c[1] += step[1];
-							outside = step[1] == 0 || c[1] < 0 || c[1] >= g.dims[1];
-							tmax[1] += tdelta[1];
-						} else {
-							c[2] += step[2];
-							outside = step[2] == 0 || c[2] < 0 || c[2] >= g.dims[2];
-							tmax[2] += tdelta[2];
-						}
-						if (outside || --guard <= 0) {
-							pflag[q] = 3u; // the walk ends after this cell unless it ends there with a hit
-							planning = false;
-						}
-					}
-					s_tnext[q][lane] = tcur;
-					s_cell[q][lane] = pcell[q];
-				}
-				u32 psp[BEAM_AHEAD], poff[BEAM_AHEAD];
-#pragma unroll
-				for (int q = 0; q < BEAM_AHEAD; q++) {
-					psp[q] = pflag[q] ? span[pcell[q]] : 0u;
-					poff[q] = pflag[q] ? offset[pcell[q]] : 0u;
-				}
-				// 2. jobs: the distinct non-empty cells of every step (a cell can only be met by rays that are in
-				//    phase, i.e. in the same step).  Lone rays with short lists test alone (flag 4).
-				if (COUNT) {
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					DDA_STAMP(0);
-				}
-				u32 nj = 0;
-#pragma unroll
-				for (int q = 0; q < BEAM_AHEAD; q++) {
-					s_sp[q][lane] = psp[q];
-					s_off[q][lane] = poff[q];
-					unsigned long long todo = __ballot(psp[q] != 0u);
-					while (todo != 0ull) {
-						const int l = (int)__builtin_ctzll(todo);
-						const u32 X = (u32)__builtin_amdgcn_readlane((int)pcell[q], l);
-						const unsigned long long grpm = __ballot(psp[q] != 0u && pcell[q] == X);
-						todo &= ~grpm;
-						const u32 S = (u32)__builtin_amdgcn_readlane((int)psp[q], l);
-						if ((grpm & (grpm - 1ull)) == 0ull && S < DDA_COOP) {
-							if (lane == l)
-								pflag[q] |= 4u;
-							continue;
-						}
-						if (lane == 0)
-							s_job[nj] = (unsigned short)((q << 8) | l);
-						nj++;
-					}
-					s_flag[q][lane] = pflag[q];
-					if (lane == 0)
-						s_jend[q] = nj;
-				}
-				njobs = nj;
-				DDA_STAMP(1);
-			}
-			// 3. the jobs in step order; the triangle ids of job j+2 and the records of job j+1 are in flight while
-			//    job j is tested
-			u32 idA = 0u, fN = 0u; // this lane's triangle of job j+2 and of job j+1
-			float rN[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#define DDA_JOB_LEN(J) (s_sp[s_job[J] >> 8][s_job[J] & 63u])
-#define DDA_JOB_BASE(J) (s_off[s_job[J] >> 8][s_job[J] & 63u])
-#define DDA_JOB_CELL(J) (s_cell[s_job[J] >> 8][s_job[J] & 63u])
-			// (every lane loads, beyond the end of a list the last triangle again, and past the last job the last
-			// job again: the number of loads in flight does not depend on the data, so the compiler can count them)
-#define DDA_JOB_ID(J) value_list[DDA_JOB_BASE(J) + min((u32)lane, DDA_JOB_LEN(J) - 1u)]
-			if (njobs > 0u) {
-				fN = DDA_JOB_ID(0u);
-				idA = DDA_JOB_ID(min(1u, njobs - 1u));
-				d_load_record<REC>(rec, verts, tris, fN, rN);
-			}
-			u32 j = 0;
-#pragma unroll 1
-			for (int q = 0; q < BEAM_AHEAD; q++) {
-				const u32 flag = s_flag[q][lane];
-				const bool here = walking && (flag & 1u);
-				const u32 sp = here ? s_sp[q][lane] : 0u, off = s_off[q][lane], cell = s_cell[q][lane];
-				const float tin = s_tin[q][lane], tnext = s_tnext[q][lane];
-				if (COUNT && here) {
-					n_cells++;
-					n_tests += sp;
-				}
-				const u32 jend = s_jend[q];
-#pragma unroll 1
-				for (; j < jend; j++) {
-					// rotate the pipeline: this job's registers, next job's records, the ids of the one after
-					u32 f0 = fN;
-					float r0[9];
-#pragma unroll
-					for (int k = 0; k < 9; k++)
-						r0[k] = rN[k];
-					// this job's operands must have arrived here, before the next loads are issued
-					asm volatile("" : "+v"(f0), "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "+v"(r0[4]), "+v"(r0[5]),
-						     "+v"(r0[6]), "+v"(r0[7]), "+v"(r0[8]), "+v"(idA));
-					DDA_STAMP(2);
-					fN = idA;
-					d_load_record<REC>(rec, verts, tris, fN, rN);
-					idA = DDA_JOB_ID(min(j + 2u, njobs - 1u));
-					const u32 X = DDA_JOB_CELL(j), base = DDA_JOB_BASE(j), S = DDA_JOB_LEN(j);
-					const bool in = sp != 0u && cell == X;
-					const unsigned long long grpm = __ballot(in);
-					if (grpm == 0ull)
-						continue; // every ray of the group ended in an earlier step of this block
-					const bool use_cull = S >= CULL_MIN;
-					BeamBox bx;
-					if (use_cull)
-						bx = d_beam_box(o, d, tin, in);
-					DDA_STAMP(3);
-					if (COUNT) {
-						st_groups++;
-						st_glanes += (u32)__popcll(grpm);
-					}
-					for (u32 b = 0; b < S; b += 64u) {
-						const bool have = b + (u32)lane < S;
-						u32 f = f0;
-						float r9[9];
-#pragma unroll
-						for (int k = 0; k < 9; k++)
-							r9[k] = r0[k];
-						if (b != 0u && have) { // lists beyond 64 triangles: the later batches are fetched here
-							f = value_list[base + b + (u32)lane];
-							d_load_record<REC>(rec, verts, tris, f, r9);
-						}
-						bool keep = have;
-						if (use_cull && have)
-							keep = !d_cull_beam(&r9[0], &r9[3], &r9[6], bx);
-						unsigned long long m = __ballot(keep);
-						DDA_STAMP(4);
-						if (COUNT && use_cull) {
-							st_cb++;
-							st_ct += (u32)__popcll(__ballot(have));
-						}
-						// survivors in list order (ascending id: the strict '<' keeps the first of equal t)
-						while (m != 0ull) {
-							const int s = (int)__builtin_ctzll(m);
-							m &= m - 1ull;
-							float bt[9];
-#pragma unroll
-							for (int k = 0; k < 9; k++)
-								bt[k] = d_readlane(r9[k], s);
-							const u32 bf = (u32)__builtin_amdgcn_readlane((int)f, s);
-							if (COUNT) {
-								st_er++;
-								st_el += (u32)__popcll(grpm);
-							}
-							if (in) {
-								const float tv[3] = { o[0] - bt[0], o[1] - bt[1], o[2] - bt[2] };
-								float t;
-								if (d_mt_core(tv, &bt[3], &bt[6], d, &t) && t > 0.0f && t < best_t) {
-									best_t = t;
-									best_id = (int)bf;
-								}
-							}
-						}
-						DDA_STAMP(5);
-					}
-				}
-				DDA_STAMP(7);
-				if (__ballot(here && (flag & 4u)) != 0ull) {
-					const u32 ns = (here && (flag & 4u)) ? sp : 0u;
-					for (u32 r = 0; r < ns; r++) {
-						const u32 f = value_list[off + r];
-						float t9[9], t;
-						d_load_triangle<REC>(rec, verts, tris, f, o[0], o[1], o[2], t9);
-						if (d_mt_core(&t9[0], &t9[3], &t9[6], d, &t) && t > 0.0f && t < best_t) {
-							best_t = t;
-							best_id = (int)f;
-						}
-						if (COUNT)
-							st_solo++;
-					}
-				}
-				DDA_STAMP(6);
-				if (here) {
-					if (best_id >= 0 && best_t <= tnext) {
-						res_t = best_t;
-						res_id = best_id;
-						walking = false;
-					} else if (flag & 2u) {
-						walking = false;
-					}
-				}
-			}
-		}
-		if (inb) {
-			hit_t[p] = res_t;
-			hit_id[p] = res_id;
-		}
-		if (COUNT) {
-			if (inb) {
-				if (n_tests)
-					atomicAdd(&counters[0], (unsigned long long)n_tests);
-				if (n_cells)
-					atomicAdd(&counters[1], (unsigned long long)n_cells);
-				atomicAdd(&counters[2], 1ull);
-				if (st_solo)
-					atomicAdd(&counters[DS_SOLO_ROUNDS], (unsigned long long)st_solo);
-			}
-			if (lane == 0) { // wave-uniform counts
-				atomicAdd(&counters[DS_ITER], (unsigned long long)st_iter);
-				atomicAdd(&counters[DS_GROUPS], (unsigned long long)st_groups);
-				atomicAdd(&counters[DS_GROUP_LANES], (unsigned long long)st_glanes);
-				atomicAdd(&counters[DS_CULL_BATCHES], (unsigned long long)st_cb);
-				atomicAdd(&counters[DS_CULL_TESTS], (unsigned long long)st_ct);
-				atomicAdd(&counters[DS_EXACT_ROUNDS], (unsigned long long)st_er);
-				atomicAdd(&counters[DS_EXACT_LANES], (unsigned long long)st_el);
-				const unsigned long long cyc = __builtin_amdgcn_s_memtime() - clk0;
-				int bucket = 0;
-				while (bucket < 15 && (cyc >> (12 + bucket)) > 1ull)
-					bucket++;
-				atomicAdd(&counters[DS_HIST_CYCLES + bucket], 1ull);
-				atomicAdd(&counters[DS_SUM_CYCLES], cyc);
-				for (int k = 0; k < 8; k++)
-					atomicAdd(&counters[DS_PHASE + k], ph[k]);
-				if (cyc >= (1ull << 20)) {
-					for (int k = 0; k < 8; k++)
-						atomicAdd(&counters[DS_PHASE_HEAVY + k], ph[k]);
-					atomicAdd(&counters[DS_PHASE_HEAVY + 8], 1ull);
-					atomicAdd(&counters[DS_PHASE_HEAVY + 9], (unsigned long long)st_er);
-					atomicAdd(&counters[DS_PHASE_HEAVY + 10], (unsigned long long)st_groups);
-					atomicAdd(&counters[DS_PHASE_HEAVY + 11], (unsigned long long)st_iter);
-				}
-				atomicMax(&counters[DS_MAX_CYCLES], cyc);
-			}
-		}
-		if (lane == 0)
-			grp = gridDim.x + atomicAdd(ticket, 1u);
-		grp = (u32)__builtin_amdgcn_readfirstlane((int)grp);
-	} // groups
-}
-
+// counters of a counting launch (UGRT_FLAG_COUNT_WORK): [0..2] tests, cells, rays (the algorithmic-byte formula), then
+// the window kernel's statistics (ugrt_dda_walk.hip: WS_*), DS_END words in all
+enum { DS_ITER = 3, DS_END = 3 + UGRT_DDA_STATS };
 
 // ugrt_dda_walk.hip
 int ugrt_dda_walk_launch(ugrt_ctx *ctx, const DGrid &g, const u32 *d_value_list, const u32 *d_span, const u32 *d_offset,
@@ -760,11 +376,10 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	const u32 bm_blocks = walk ? ((ncell_all + 255u) / 256u < 1024u ? (ncell_all + 255u) / 256u : 1024u) : 0u;
 	// launch shape (ugrt_ctx_set_option; no effect on results): which kernel, rays per wave, list length from
 	// which a lone ray's cell is tested by the whole wave, list length from which a shared cell is culled first
-	// 0 window, 1 per-ray, 2 beam (the window kernel packs the steps left per axis into 10 bits each: ugrt_ctx_create
-	// admits at most 1024 cells per axis)
+	// 0 window, 1 per-ray (the window kernel packs the steps left per axis into 10 bits each: ugrt_ctx_create admits at
+	// most 1024 cells per axis)
 	const int kernel = ctx->opt[UGRT_OPT_DDA_KERNEL] > 0 ? ctx->opt[UGRT_OPT_DDA_KERNEL] : 0;
-	const bool beam = kernel != 1;
-	u32 DDA_RPW = ctx->opt[UGRT_OPT_DDA_RPW] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_RPW] : (kernel == 2 ? 64u : 32u);
+	u32 DDA_RPW = ctx->opt[UGRT_OPT_DDA_RPW] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_RPW] : 32u;
 	const u32 DDA_COOP = ctx->opt[UGRT_OPT_DDA_COOP] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_COOP] : 8u;
 	const u32 CULL_MIN = ctx->opt[UGRT_OPT_DDA_CULL_MIN] > 0 ? (u32)ctx->opt[UGRT_OPT_DDA_CULL_MIN] : 8u;
 	if (DDA_RPW > 64u)
@@ -833,18 +448,9 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 		return UGRT_OK;
 	}
 #define UGRT_LAUNCH_DDA(CNTV, RECV, DC)                                                                               \
-	do {                                                                                                          \
-		if (beam)                                                                                             \
-			hipLaunchKernelGGL((k_trace_dda_beam<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g,  \
-					   d_value_list, d_span, d_offset, d_vertlist, d_trilist, rec, d_rays,         \
-					   (const u32 *)list, (const u32 *)dcount, d_hit_t, d_hit_id, DC, DDA_RPW,     \
-					   DDA_COOP, CULL_MIN, ctx->d_small + UGRT_DSMALL_TICKET);                                                      \
-		else                                                                                                  \
-			hipLaunchKernelGGL((k_trace_dda_ray<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g,   \
-					   d_value_list, d_span, d_offset, d_vertlist, d_trilist, rec, d_rays,         \
-					   (const u32 *)list, (const u32 *)dcount, d_hit_t, d_hit_id, DC, DDA_RPW,     \
-					   DDA_COOP);                                                                  \
-	} while (0)
+	hipLaunchKernelGGL((k_trace_dda_ray<CNTV, RECV>), dim3(blocks), dim3(64), 0, ctx->stream, g, d_value_list, d_span,    \
+			   d_offset, d_vertlist, d_trilist, rec, d_rays, (const u32 *)list, (const u32 *)dcount, d_hit_t,     \
+			   d_hit_id, DC, DDA_RPW, DDA_COOP)
 	if (counting) {
 		// counting variant (never the timed one): same traversal + atomics per ray / per wave
 		UGRT_HIP(hipMemsetAsync(dc, 0, DS_END * sizeof(unsigned long long), ctx->stream));
@@ -873,11 +479,10 @@ extern "C" int ugrt_trace_dda(ugrt_ctx *ctx, const unsigned *d_value_list, const
 	return UGRT_OK;
 }
 
-// work sharing of the beam kernel's last counting launch (UGRT_FLAG_COUNT_WORK): [0] wave iterations (blocks of
-// BEAM_AHEAD steps), [1] cell groups processed, [2] rays in those groups, [3] cull batches, [4] triangles culled
-// against a bundle, [5] exact-test rounds (one broadcast triangle), [6] rays that ran those rounds,
-// [7] exact tests of lone rays, [8..23] waves by log2(shader cycles / 4096), [24] sum and [25] maximum of the
-// waves' cycles
+// work sharing of the window kernel's last counting launch (UGRT_FLAG_COUNT_WORK), in the order of ugrt_dda_walk.hip's
+// WS_* enum: windows, jobs, rays in jobs, cull batches, triangles culled against a bundle, exact-test rounds,
+// (survivor, ray) pairs of those rounds, empty windows, [8..23] waves by log2(shader cycles / 4096), [24] sum and [25]
+// maximum of the waves' cycles, then the cycles per phase
 extern "C" int ugrt_stats_dda(ugrt_ctx *ctx, unsigned long long *stats, int n)
 {
 	if (!ctx || !stats || n < 0)

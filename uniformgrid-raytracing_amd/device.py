@@ -259,9 +259,6 @@ class Context:
         check(lib.ugrt_stats_get(self._h, a))
         return list(a)
 
-    DDA_STATS = ("wave_iterations", "cell_groups", "group_rays", "cull_batches", "cull_tests", "exact_rounds",
-                 "exact_round_rays", "lone_ray_tests")
-
     PRIMARY_STATS = ("items", "batches", "batches_with_tile_survivors", "references", "tile_survivors",
                      "quadrant_survivors", "jobs", "flushes", "rounds", "rounds_to_division", "rounds_to_v",
                      "rounds_to_t", "lane_tests", "hits", "jobs_behind_the_flush_s_final_hits", "jobs_dropped_by_the_depth_bound")
@@ -282,19 +279,13 @@ class Context:
         return dict(zip(("segments", "jobs_of_the_launch_before", "groups_walked_again", "rays_walked_again"), list(a)))
 
     def stats_dda(self, kernel=0):
-        """Work sharing of the bounce kernel's last counting launch (a FLAG_COUNT_WORK context); `kernel` = the
-        "dda_kernel" option it ran with (0 window kernel, 2 beam kernel of round 2: the counters' meanings differ)."""
+        """Work sharing of the window kernel's last counting launch (a FLAG_COUNT_WORK context, "dda_kernel" 0)."""
         a = (C.c_ulonglong * 46)()
         check(lib.ugrt_stats_dda(self._h, a, 46))
-        walk = kernel == 0
-        d = dict(zip(self.WALK_STATS if walk else self.DDA_STATS, list(a)[:8]))
+        d = dict(zip(self.WALK_STATS, list(a)[:8]))
         d["waves_by_log2_cycles_over_4096"] = list(a)[8:24]
         d["cycles_sum"], d["cycles_max"] = a[24], a[25]
-        phases = (("plan_bitmap", "job_list_headers", "operand_arrival", "box", "cull", "exact_rounds", "settle", "rest")
-                  if walk else ("plan_headers", "job_list", "operand_arrival", "box", "cull", "exact_rounds", "lone_rays",
-                                "rest"))
+        phases = ("plan_bitmap", "job_list_headers", "operand_arrival", "box", "cull", "exact_rounds", "settle", "rest")
         d["phase_cycles"] = dict(zip(phases, list(a)[26:34]))
-        d["heavy_waves" if not walk else "waves_of_2e19_cycles_or_more"] = dict(
-            zip(phases + ("waves", "rounds", "jobs" if walk else "groups", "windows" if walk else "iterations"),
-                list(a)[34:46]))
+        d["waves_of_2e19_cycles_or_more"] = dict(zip(phases + ("waves", "rounds", "jobs", "windows"), list(a)[34:46]))
         return d

@@ -336,6 +336,9 @@ def main():
                     help="the light grid and the uniform grid are built as one batch whose sorts share their launches "
                          "(ugrt_grid_build_batch_begin / _end: three radix launches less per frame; measured 2 %% slower with "
                          "four frames in flight, profiles/r04_batched_builds.txt; default: one after the other)")
+    ap.add_argument("--bands-in-frame", type=int, nargs="*", default=[2, 3],
+                    help="N = 1: also time ONE frame at a time cut into this many bands of tile rows on streams of their own "
+                         "(BandedRenderer; reported under one_frame_in_bands; none = skip)")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()
@@ -823,6 +826,40 @@ def main():
         except Exception as e:  # the baseline is a report, never a reason to lose the measurement
             cpu = dict(value=None, unit="Mrays/s", cores=0, kind="port", sample="failed: %r" % (e,))
 
+    # one frame at a time, cut into bands of tile rows on streams of their own (renderer.BandedRenderer): the light grid,
+    # the uniform grid and the bounce whole on one side context.  Verified against the renderers' frame.
+    banded = None
+    if world == 1 and args.bands_in_frame and reflect and not args.animate and shards is None and not args.no_overlap:
+        banded = {}
+        try:
+            for nb in args.bands_in_frame:
+                br = ugrt.BandedRenderer(ugrt.Context, W, H, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"],
+                                         bands=nb, device=local, light_grid=lg, uniform_dims=udims, flags=flags)
+                for _ in range(6):
+                    br.display(setup, shadows=True, reflect=True)
+                br.synchronize()
+                torch.cuda.synchronize()
+                times = []
+                for _ in range(3):
+                    r0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        br.display(setup, shadows=True, reflect=True)
+                    br.synchronize()
+                    torch.cuda.synchronize()
+                    times.append((time.perf_counter() - r0) / args.steps * 1e3)
+                names = ["image", "is_shadowed", "intersect_id", "t", "normal", "dir", "hit_t", "hit_id", "active"]
+                same = all(bool(torch.equal(getattr(br, k).view(torch.uint8), getattr(renderers[0], k).view(torch.uint8)))
+                           for k in names) if not args.animate else None
+                banded["bands_%d" % nb] = {"ms_per_step": round(times[0], 4), "repeat_ms_per_step": [round(x, 4) for x in times[1:]],
+                                           "equal_to_the_timed_renderers_frame": same}
+                if same is False:
+                    failed = True
+                del br
+                gc.collect()
+        except Exception as e:
+            banded["error"] = repr(e)
+            failed = True
+
     # the other BASELINE configurations, in this same process, behind the headline measurement (each verified)
     other = None
     default_run = (world == 1 and args.workload == "crash" and args.scale == 1.0 and not (args.width or args.height) and reflect
@@ -914,6 +951,7 @@ def main():
         "band_balance_rounds": balance_log if world > 1 else None,
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},
         "other_configs": other,
+        "one_frame_in_bands": banded,
     }
     if failed:
         line["error"] = ("verification failed: the timed frames differ from the sequential waiting-build context in %r; "

@@ -1047,6 +1047,34 @@ def test_batched_light_and_uniform_builds(ugrt, O, torch, name, W, H, lg, ud):
         r.aux.grid_build_batch_end()  # no batch is open
 
 
+@pytest.mark.parametrize("name,W,H,bands", [("crash", 384, 216, 2), ("crash", 384, 216, 3), ("hall", 256, 256, 4)])
+def test_banded_frame_equals_the_single_context_frame(ugrt, O, torch, name, W, H, bands):
+    """BandedRenderer: ONE frame at a time, cut into bands of tile rows on streams of their own, the light grid, the
+    uniform grid and the bounce whole on one side context; every band writes its rows of the same arrays.  Several
+    frames (the first in the waiting form, then the asynchronous one, no host wait inside a frame): all buffers equal
+    the CPU restatement's full frame, bit for bit."""
+    s = scene(ugrt, name)
+    lg, ud = (64, 64), (32, 32, 16)
+    setup = setup_for(ugrt, s, "ref")
+    want = O.frame(s, setup, W, H, light_grid=lg, reflect=True, uniform_dims=ud, all_chunks=True)
+    br = ugrt.BandedRenderer(ugrt.Context, W, H, s["verts"], s["faces"], s["matidx"], s["mat_list"], s["reflect"], bands=bands,
+                             light_grid=lg, uniform_dims=ud, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS)
+    for k in range(4):
+        br.display(setup, shadows=True, reflect=True)
+        if k != 2:  # (frames 2 and 3 are enqueued back to back)
+            br.synchronize()
+            torch.cuda.synchronize()
+            what = "frame %d" % k
+            np.testing.assert_array_equal(br.intersect_id.cpu().numpy(), want["mat_ids"], err_msg=what)
+            assert_bits_equal(br.t.cpu().numpy(), want["primary"]["t"], "t, " + what)
+            assert_bits_equal(br.normal.cpu().numpy(), want["primary"]["normal"].reshape(-1), "normal, " + what)
+            np.testing.assert_array_equal(br.is_shadowed.cpu().numpy(), want["is_shadowed"], err_msg=what)
+            np.testing.assert_array_equal(br.active.cpu().numpy(), want["active"], err_msg=what)
+            np.testing.assert_array_equal(br.hit_id.cpu().numpy(), want["hit_id"], err_msg=what)
+            assert_bits_equal(br.hit_t.cpu().numpy(), want["hit_t"], "bounce t, " + what)
+            np.testing.assert_array_equal(br.image.cpu().numpy(), want["image"], err_msg=what)
+
+
 def bits_for_cells(c):
     b = 1
     while (1 << b) < c:

@@ -179,4 +179,4 @@ def _f3(v):
 from .host import Model, Camera, write_ppm  # noqa: E402
 from .device import Context  # noqa: E402
 from . import scenes  # noqa: E402
-from .renderer import Renderer, FrameSetup  # noqa: E402
+from .renderer import Renderer, FrameSetup, BandedRenderer  # noqa: E402

@@ -444,3 +444,140 @@ class Renderer:
         """uint8 view [rows*8, W, 3] of this context's band."""
         ctx = self.ctx
         return self.image[3 * ctx.p0:3 * (ctx.p0 + ctx.npix)].view(-1, ctx.width, 3)
+
+
+class BandedRenderer:
+    """ONE frame at a time, cut into bands of tile rows that run on HIP streams of their own (SURVEY 8(e)'s sharding,
+    applied to the streams of one GPU instead of to GPUs).
+
+    A frame alone cannot fill the chip: its main stream is a chain of ~45 dependent launches, most of them short and
+    latency-bound (the sorts' passes, scans, run and item kernels), and only the three tracers are wide.  With B band
+    contexts the chains of the bands run beside each other; the light grid, the uniform grid and the bounce stay whole
+    on ONE side context (they depend on the geometry, not on the band).  Every band context writes its rows of the SAME
+    per-pixel arrays (pixel ids are global: a band context writes its band), so the frame's buffers are those of a
+    single-context frame, bit for bit (tests/test_gpu_parity.py::test_banded_frame_equals_the_single_context_frame).
+
+        side:    light grid, uniform grid .................. (all primaries) secondary rays, 3D-DDA
+        band i:  screen grid (rows of the band), primary ... ray map + sort, (grids) shadow pass, (DDA) shading
+
+    No call waits for the device (option async_build on every context); one host thread enqueues the stages band by
+    band."""
+
+    def __init__(self, Context, W, H, verts, faces, matidx, mat_list, reflect=None, bands=2, device=0, light_grid=(128, 128),
+                 uniform_dims=(128, 128, 64), flags=0):
+        from . import parallel
+
+        assert bands >= 1
+        self.bands = bands
+        nby = H // 8
+        import torch as t
+
+        self.torch = t
+        dev = t.device("cuda", device)
+        self.main_stream = t.cuda.current_stream(dev)
+        self.side_stream = t.cuda.Stream(dev)
+        with t.cuda.stream(self.side_stream):
+            self.aux = Context(W, H, device=device, light_grid=light_grid, flags=flags, uniform_dims=uniform_dims)
+        self.streams, self.rs = [], []
+        bounds = parallel.equal_bounds(bands, nby)
+        for b in range(bands):
+            st = self.main_stream if b == 0 else t.cuda.Stream(self.aux.device)
+            with t.cuda.stream(st):
+                cx = Context(W, H, device=device, light_grid=light_grid, rows=(bounds[b], bounds[b + 1]), flags=flags,
+                             uniform_dims=uniform_dims)
+                r = Renderer(cx, verts, faces, matidx, mat_list, reflect)
+            self.streams.append(st)
+            self.rs.append(r)
+        r0 = self.rs[0]
+        r0._ensure_reflect_buffers()
+        shared = ("normal", "t", "dir", "is_shadowed", "intersect_id", "image", "rays", "active", "hit_t", "hit_id", "d_verts",
+                  "d_faces", "d_matidx", "d_matlist", "d_reflect")
+        for r in self.rs[1:]:
+            for name in shared:
+                setattr(r, name, getattr(r0, name))
+        for name in shared:
+            setattr(self, name, getattr(r0, name))
+        self.F, self.num_materials, self.bbmin, self.bbmax, self.aspect = r0.F, r0.num_materials, r0.bbmin, r0.bbmax, r0.aspect
+        for c in [self.aux] + [r.ctx for r in self.rs]:
+            c.set_option("async_build", 1)
+        # (as in the two-stream frame: the bounce's persistent waves leave room for the bands' short kernels)
+        self.aux.set_option("dda_blocks", 1024)
+
+    def contexts(self):
+        return [self.aux] + [r.ctx for r in self.rs]
+
+    def display(self, setup, frame_cnt=1, shadows=True, reflect=True):
+        t, aux, main, side = self.torch, self.aux, self.main_stream, self.side_stream
+        r0 = self.rs[0]
+        cam = make_camera(setup.camera, setup.fovy, self.aspect)
+        lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
+        ev_grids, ev_dda = t.cuda.Event(), t.cuda.Event()
+        ev_prim = [t.cuda.Event() for _ in self.rs]
+        for st in self.streams[1:] + [side]:
+            st.wait_stream(main)  # the geometry of this frame (and the last frame's readers) are behind the main stream
+        with t.cuda.stream(side):
+            if shadows:
+                aux.upload_camera(lcam.camcoords)
+                aux.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
+            if reflect:
+                aux.grid_build_uniform(self.d_faces, self.d_verts, self.F, self.bbmin, self.bbmax)
+            ev_grids.record(side)
+        for r, st, ev in zip(self.rs, self.streams, ev_prim):
+            with t.cuda.stream(st):
+                ctx = r.ctx
+                ctx.set_light_position(setup.shading_light)
+                r._upload_cam_pos(cam.worldori)
+                ctx.upload_camera(cam.camcoords)
+                ctx.grid_build_perspective(self.d_faces, self.d_verts, self.F)
+                value, span, offset, _ = ctx.grid_ptrs(GRID_PERSPECTIVE)
+                ctx.trace_primary(value, span, offset, self.normal, self.t, self.dir, self.is_shadowed, self.intersect_id,
+                                  self.d_verts, self.d_faces)
+                ev.record(st)
+        if reflect:
+            with t.cuda.stream(side):
+                for ev in ev_prim:
+                    side.wait_event(ev)
+                aux.reflect_rays(r0.cam_pos, self.t, self.dir, self.intersect_id, self.d_matidx, self.d_reflect,
+                                 self.num_materials, self.d_verts, self.d_faces, r0.reflect_eps, self.rays, self.active)
+                uvalue, uspan, uoffset, _ = aux.grid_ptrs(GRID_UNIFORM)
+                aux.trace_dda(uvalue, uspan, uoffset, self.d_verts, self.d_faces, self.rays, self.active, self.hit_t, self.hit_id)
+                ev_dda.record(side)
+        for r, st in zip(self.rs, self.streams):
+            with t.cuda.stream(st):
+                ctx = r.ctx
+                ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
+                if shadows:
+                    ctx.map_rays_to_light(self.t, self.dir, r.d_map, r.cam_pos, PI_F, PI_F)
+                    r._num_chunks = ctx.sort_rays(r.d_map, r.prefix, deferred=True)
+                    st.wait_event(ev_grids)
+                    lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
+                    ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
+                                     r.d_map, r.prefix, r.cam_pos, r._num_chunks)
+        for r, st in zip(self.rs, self.streams):
+            with t.cuda.stream(st):
+                ctx = r.ctx
+                if reflect:
+                    st.wait_event(ev_dda)
+                    ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, r.cam_pos, self.d_matidx,
+                                      self.d_matlist, self.d_reflect, self.num_materials, self.d_verts, self.d_faces, self.rays,
+                                      self.active, self.hit_t, self.hit_id)
+                elif frame_cnt < 2:
+                    ctx.shade_simple(self.image, self.normal, self.t, self.dir, self.intersect_id, r.cam_pos, self.d_matidx,
+                                     self.d_matlist, self.num_materials)
+                else:
+                    ctx.shade_spotlight(self.image, self.normal, self.t, self.dir, self.intersect_id, r.cam_pos, self.d_matidx,
+                                        self.d_matlist, self.num_materials)
+                if shadows:
+                    ctx.shade_add_shadows(self.image, self.is_shadowed)
+        for st in self.streams[1:] + [side]:
+            main.wait_stream(st)
+
+    def synchronize(self):
+        err = None
+        for c in self.contexts():
+            try:
+                c.synchronize()
+            except Exception as e:  # UGRT_EOVERFLOW of any context: one report for the frame
+                err = err or e
+        if err is not None:
+            raise err

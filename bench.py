@@ -336,9 +336,11 @@ def main():
                     help="the light grid and the uniform grid are built as one batch whose sorts share their launches "
                          "(ugrt_grid_build_batch_begin / _end: three radix launches less per frame; measured 2 %% slower with "
                          "four frames in flight, profiles/r04_batched_builds.txt; default: one after the other)")
-    ap.add_argument("--bands-in-frame", type=int, nargs="*", default=[2, 3],
+    ap.add_argument("--bands-in-frame", type=int, nargs="*", default=[],
                     help="N = 1: also time ONE frame at a time cut into this many bands of tile rows on streams of their own "
-                         "(BandedRenderer; reported under one_frame_in_bands; none = skip)")
+                         "(BandedRenderer; reported under one_frame_in_bands).  Default: none -- measured: 2 bands 1.45 against "
+                         "1.46 ms, 3 and 4 bands 2.0 ms (the one host thread then enqueues 160-200 launches a frame at ~6 us "
+                         "each: profiles/r04_banded_frame.txt)")
     ap.add_argument("--animate", action="store_true",
                     help="BASELINE configs[4]: transform the animated sub-range every frame (rot = 1.81 + 0.05*frame)")
     args = ap.parse_args()

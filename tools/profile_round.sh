@@ -17,11 +17,11 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 python3 tools/kernel_resources.py -o $OUT/kernel_resources.txt > /dev/null
 python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 "$@" > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --repeats 0 --bands-in-frame --no-verify --no-other-configs "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --bands-in-frame --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --bands-in-frame --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/write.err
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/sq -o q --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --bands-in-frame --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/sq.err
-rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM -d $OUT/sq2 -o q2 --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --bands-in-frame --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/sq2.err
-rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/l2 -o l --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --bands-in-frame --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/l2.err || true
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --repeats 0 --no-verify --no-other-configs "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/sq -o q --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/sq.err
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM -d $OUT/sq2 -o q2 --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/sq2.err
+rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/l2 -o l --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --repeats 0 --no-verify --no-other-configs "$@" > /dev/null 2> $OUT/l2.err || true
 rm -f $OUT/*/*agent_info.csv
 ls $OUT/*

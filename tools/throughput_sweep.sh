@@ -1,7 +1,7 @@
 #!/bin/bash
 # Launch-shape sweep of the default bench frame (4 frames in flight): which settings of bench.py's constants still hold
 # after a round's kernel changes?   tools/throughput_sweep.sh > gpurun_out/throughput_sweep.txt
-B="python3 bench.py --cpu-seconds 0 --no-other-configs --bands-in-frame --no-verify --repeats 2 --steps 20 --warmup 5"
+B="python3 bench.py --cpu-seconds 0 --no-other-configs --no-verify --repeats 2 --steps 20 --warmup 5"
 run() { tag=$1; shift; out=$("$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(d['ms_per_step'], d['repeat_ms_per_step'], d['ms_per_step_one_frame_in_flight'], d['stages_ms_per_step'].get('trace_dda'))"); echo "$tag: $out"; }
 run default $B
 run dda_split=1 $B --opt dda_split=1

@@ -73,7 +73,45 @@ def pmc_traffic(workload, W, H, scale, kernel):
     return per, ent, None
 
 
-def load_scene(ugrt, workload, scale, rank):
+def cpp_driver_leg(ugrt, torch, s, W, H, image, frames=40, time_from=10):
+    """The frame loop in C++ (integration/display_main: display() of main.cu over the shim classes, two streams, one
+    frame at a time, no Python in the process), started as a child process on the scene files of this run: its own
+    ms per frame, and its PPM against the timed renderers' image."""
+    import subprocess
+
+    import numpy as np
+
+    exe = os.path.join(ROOT, "integration", "display_main")
+    if not os.path.exists(exe) or "files" not in s:
+        return None
+    d = s["files"]["dir"]
+    cam, lcam = s["cameras"]["ref"], s["light_camera"]
+    flat = lambda c: " ".join("%.9g" % v for v in (list(c["eye"]) + list(c["look"]) + list(c["up"]) + [c["near"], c["far"]]))
+    params, out = os.path.join(d, "params.txt"), os.path.join(d, "out.ppm")
+    with open(params, "w") as f:
+        f.write("obj %s\nmat %s\nsize %d %d\ncamera %s\nlight_camera %s\nshading_light %s\nstreams 2\nreflect 1\nframes %d\n"
+                "time_from %d\nflags %d\n" % (s["files"]["obj"], s["files"]["mat"], W, H, flat(cam), flat(lcam),
+                                             " ".join("%.9g" % v for v in s["shading_light"]), frames, time_from,
+                                             ugrt.FLAG_SHADOW_ALL_CHUNKS | ugrt.FLAG_STATIC_GEOMETRY))
+    t0 = time.time()
+    p = subprocess.run([exe, params, out], cwd=d, capture_output=True, text=True, timeout=300)
+    res = {"rc": p.returncode, "wall_s": round(time.time() - t0, 1), "streams": 2, "frames_in_flight": 1,
+           "what": "integration/display_main (C++ over the C-ABI, no Python): %d frames, the last %d timed as a whole"
+                   % (frames, frames - time_from)}
+    if p.returncode != 0:
+        res["error"] = (p.stdout + p.stderr)[-400:]
+        return res
+    for line in p.stdout.splitlines():
+        w = line.split()
+        if len(w) == 4 and w[0] == "timed_frames":
+            res["ms_per_frame"] = float(w[3])
+    tok = open(out).read().split()
+    got = np.array(tok[4:], dtype=np.int64).astype(np.uint8)
+    res["ppm_equals_the_timed_renderers_image"] = bool(np.array_equal(got, image.cpu().numpy()))
+    return res
+
+
+def load_scene(ugrt, workload, scale, rank, keep_files=False):
     """Generate the procedural scene, write it as .obj/.mtl/.mat and load it through the product's loader."""
     t0 = time.time()
     d = tempfile.mkdtemp(prefix="ugrt_bench_r%d_" % rank)
@@ -88,9 +126,16 @@ def load_scene(ugrt, workload, scale, rank):
     s["matidx"] = m.h_materiallist_index
     s["mat_list"] = m.h_materiallist.reshape(-1, 6)
     s["reflect"] = m.h_reflectlist
-    for f in (info["obj"], info["mtl"], info["mat"]):
-        os.unlink(f)
-    os.rmdir(d)
+    if keep_files:  # (the C++ driver's leg loads the same files; removed at exit)
+        import atexit
+        import shutil
+
+        s["files"] = {"dir": d, "obj": info["obj"], "mtl": info["mtl"], "mat": info["mat"]}
+        atexit.register(shutil.rmtree, d, True)
+    else:
+        for f in (info["obj"], info["mtl"], info["mat"]):
+            os.unlink(f)
+        os.rmdir(d)
     log("[bench] rank %d: scene %s: %d triangles, generated + written + parsed in %.1f s"
         % (rank, info["name"], s["num_faces"], time.time() - t0))
     return s
@@ -394,7 +439,7 @@ def main():
     if args.uniform_grid:
         udims = tuple(args.uniform_grid)
 
-    s = load_scene(ugrt, args.workload, args.scale, rank)
+    s = load_scene(ugrt, args.workload, args.scale, rank, keep_files=(world == 1 and args.other_configs))
     setup = ugrt.FrameSetup.from_scene(s)
     # the renderer is the only writer of the vertex array (ugrt_animate): triangle records survive between builds
     flags = ugrt.FLAG_SHADOW_ALL_CHUNKS | (0 if args.no_static_geometry else ugrt.FLAG_STATIC_GEOMETRY)
@@ -862,6 +907,16 @@ def main():
             banded["error"] = repr(e)
             failed = True
 
+    # the same frame from the C++ host (child process), one frame at a time
+    cpp = None
+    if world == 1 and args.other_configs and reflect and not args.animate and args.scale == 1.0 and not (args.width or args.height):
+        try:
+            cpp = cpp_driver_leg(ugrt, torch, s, W, H, renderers[0].image)
+        except Exception as e:
+            cpp = {"error": repr(e)}
+        if cpp and cpp.get("ppm_equals_the_timed_renderers_image") is False:
+            failed = True
+
     # the other BASELINE configurations, in this same process, behind the headline measurement (each verified)
     other = None
     default_run = (world == 1 and args.workload == "crash" and args.scale == 1.0 and not (args.width or args.height) and reflect
@@ -954,6 +1009,7 @@ def main():
         "algorithmic_bytes": {k: int(v) for k, v in abytes.items()},
         "other_configs": other,
         "one_frame_in_bands": banded,
+        "cpp_driver": cpp,
     }
     if failed:
         line["error"] = ("verification failed: the timed frames differ from the sequential waiting-build context in %r; "

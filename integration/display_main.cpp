@@ -64,7 +64,7 @@ int frame_cnt = 0;
 struct Params {
 	char obj[512], mat[512];
 	float cam[11], light[11]; // eye, look, up, near, far
-	int streams, reflect, frames, animate_size, animate_offset, ranks, rendezvous_timeout;
+	int streams, reflect, frames, animate_size, animate_offset, ranks, rendezvous_timeout, time_from;
 	unsigned flags;
 } P;
 
@@ -76,7 +76,7 @@ static void read_params(const char *path)
 		exit(1);
 	}
 	char key[64];
-	P.streams = 1, P.frames = 1, P.ranks = 0, P.rendezvous_timeout = 60;
+	P.streams = 1, P.frames = 1, P.ranks = 0, P.rendezvous_timeout = 60, P.time_from = 0;
 	while (fscanf(fp, "%63s", key) == 1) {
 		if (!strcmp(key, "obj"))
 			(void)!fscanf(fp, "%511s", P.obj);
@@ -100,6 +100,8 @@ static void read_params(const char *path)
 			(void)!fscanf(fp, "%d", &P.frames);
 		else if (!strcmp(key, "ranks"))
 			(void)!fscanf(fp, "%d", &P.ranks);
+		else if (!strcmp(key, "time_from"))
+			(void)!fscanf(fp, "%d", &P.time_from);
 		else if (!strcmp(key, "rendezvous_timeout"))
 			(void)!fscanf(fp, "%d", &P.rendezvous_timeout);
 		else if (!strcmp(key, "flags"))
@@ -463,7 +465,16 @@ int main(int argc, char **argv)
 		d_hit_id = dev_alloc<int>(N);
 	}
 	unsigned char *d_gather = comm && rank == 0 ? dev_alloc<unsigned char>(3 * N) : nullptr;
+	// `time_from F` (F > 0): the frames from frame F on are timed as a whole (the streams are drained before frame F and
+	// behind the last one; the frames before are the warm-up that sizes the asynchronous builds)
+	double t_begin = 0.0;
 	for (int f = 0; f < P.frames; f++) {
+		if (P.time_from > 0 && f == P.time_from) {
+			HIP_CHECK(hipStreamSynchronize(g_main));
+			if (g_side)
+				HIP_CHECK(hipStreamSynchronize(g_side));
+			t_begin = now_s();
+		}
 		display();
 		if (comm) {
 			// the frame's one collective: every rank's band of RGB rows to rank 0, in stream order behind the shading
@@ -479,6 +490,13 @@ int main(int argc, char **argv)
 				}
 			NCCL_CHECK(ncclGroupEnd());
 		}
+	}
+	double ms_per_frame = 0.0;
+	if (P.time_from > 0 && P.frames > P.time_from) {
+		HIP_CHECK(hipStreamSynchronize(g_main));
+		if (g_side)
+			HIP_CHECK(hipStreamSynchronize(g_side));
+		ms_per_frame = (now_s() - t_begin) * 1e3 / (double)(P.frames - P.time_from);
 	}
 	if (rank == 0)
 		HIP_CHECK(hipMemcpyAsync(h_image, comm ? d_gather : d_image, 3 * N, hipMemcpyDeviceToHost, g_main)); // main.cu:244
@@ -502,5 +520,7 @@ int main(int argc, char **argv)
 	}
 	writePPM(argv[2]);
 	printf("frames %d streams %d ranks %d chunks %zu\n", frame_cnt, P.streams, ranks, *dData->h_numCudaBlocks);
+	if (ms_per_frame > 0.0)
+		printf("timed_frames %d ms_per_frame %.4f\n", P.frames - P.time_from, ms_per_frame);
 	return 0;
 }

@@ -223,6 +223,37 @@ __device__ __forceinline__ bool d_cull_cr(const CullTri &t, const CBox &bx)
 	return false;
 }
 
+// The same test against four boxes that share one half width (the quadrants of a tile: their radii differ by a few per
+// cent, the largest is taken for all -- a larger box only culls less): the radius terms are formed once instead of four
+// times (~100 instead of ~180 instructions per batch with survivors).  Bit q of the result = box q cannot be hit.
+__device__ __forceinline__ u32 d_cull_cr4(const CullTri &t, const CBox *bx, const float *r)
+{
+#pragma clang fp contract(fast)
+	const float Dr = fabsf(t.nD[0]) * r[0] + fabsf(t.nD[1]) * r[1] + fabsf(t.nD[2]) * r[2];
+	const float Ar = fabsf(t.nA[0]) * r[0] + fabsf(t.nA[1]) * r[1] + fabsf(t.nA[2]) * r[2];
+	const float Br = fabsf(t.nB[0]) * r[0] + fabsf(t.nB[1]) * r[1] + fabsf(t.nB[2]) * r[2];
+	const float Cr = fabsf(t.nC[0]) * r[0] + fabsf(t.nC[1]) * r[1] + fabsf(t.nC[2]) * r[2];
+	const float mC = t.mA + t.mB + t.mD;
+	u32 culled = 0u;
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const float *c = bx[q].c;
+		const float Dm = t.nD[0] * c[0] + t.nD[1] * c[1] + t.nD[2] * c[2];
+		bool out = false;
+		if (Dm + Dr < 1e15f && Dm - Dr > -1e15f) {
+			const float Am = t.nA[0] * c[0] + t.nA[1] * c[1] + t.nA[2] * c[2];
+			const float Bm = t.nB[0] * c[0] + t.nB[1] * c[1] + t.nB[2] * c[2];
+			const float Cm = t.nC[0] * c[0] + t.nC[1] * c[1] + t.nC[2] * c[2];
+			if (Dm - Dr > t.mD) // det > 0 for every direction of the box
+				out = (Am + Ar < -t.mA) || (Bm + Br < -t.mB) || (Cm - Cr > mC);
+			else if (Dm + Dr < -t.mD) // det < 0
+				out = (Am - Ar > t.mA) || (Bm - Br > t.mB) || (Cm + Cr < -mC);
+		}
+		culled |= out ? (1u << q) : 0u;
+	}
+	return culled;
+}
+
 __device__ __forceinline__ float d_readlane(float v, int l)
 {
 	return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));

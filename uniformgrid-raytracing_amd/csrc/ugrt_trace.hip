@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 		// centre and half width are formed per lane and read from one lane of each quadrant, so that
 		// the boxes live in scalar registers
 		CBox qb[4], tb;
+		float qrmax[3]; // the largest of the four quadrants' half widths, per component (d_cull_cr4)
 #pragma unroll
 		for (int k = 0; k < 3; k++) {
 			float lo = dir[k], hi = dir[k];
@@ -263,6 +264,11 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 			}
 			const float qc = 0.5f * (lo + hi);
 			const float qr = 0.5f * (hi - lo) * 1.0001f + 1e-6f; // far more than the rounding of c and r
+			{
+				float m = fmaxf(qr, __shfl_xor(qr, 4));
+				m = fmaxf(m, __shfl_xor(m, 32));
+				qrmax[k] = d_readlane(m, 0);
+			}
 			lo = fminf(lo, __shfl_xor(lo, 4));
 			hi = fmaxf(hi, __shfl_xor(hi, 4));
 			lo = fminf(lo, __shfl_xor(lo, 32));
@@ -315,9 +321,10 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 					float tlow = 0.0f;
 					if (keep) {
 						tlow = d_cull_tlow(ct, &t9[6], tb);
+						const u32 out4 = d_cull_cr4(ct, qb, qrmax);
 #pragma unroll
 						for (int q = 0; q < 4; q++)
-							km |= (d_cull_cr(ct, qb[q]) || tlow > qfar[q]) ? 0u : (1u << q);
+							km |= (((out4 >> q) & 1u) || tlow > qfar[q]) ? 0u : (1u << q);
 					}
 					if (COUNT)
 						ps[PS_BATCHES_KEPT]++;

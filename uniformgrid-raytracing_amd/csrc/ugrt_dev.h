@@ -178,6 +178,34 @@ __device__ __forceinline__ bool d_mt_core(const float *tvec, const float *edge1,
 	return true;
 }
 
+// The same test for rays that SHARE their origin (a light's shadow rays): tvec is then the triangle's own, and so are
+// qvec = tvec x edge1 and T = edge2 . qvec, which d_mt_core forms anew for every ray.  They are formed once per triangle
+// (d_mt_shared: the same operations in the same order, so the same floats) and every ray's test starts from them:
+// 14 operations less per (triangle, ray) pair, results bit for bit those of d_mt_core.
+__device__ __forceinline__ void d_mt_shared(const float *tvec, const float *edge1, const float *edge2, float *qvec, float *T)
+{
+	D_CROSS(qvec, tvec, edge1);
+	*T = D_DOT(edge2, qvec);
+}
+__device__ __forceinline__ bool d_mt_core_shared(const float *tvec, const float *edge1, const float *edge2, const float *qvec, float T,
+						 const float *dir, float *t_out)
+{
+	float pvec[3];
+	D_CROSS(pvec, dir, edge2);
+	float det = D_DOT(edge1, pvec);
+	if (det > -D_EPSILON && det < D_EPSILON)
+		return false;
+	float inv_det = 1.0f / det;
+	float u = D_DOT(tvec, pvec) * inv_det;
+	if (u < 0.0f || u > 1.0f)
+		return false;
+	float v = D_DOT(dir, qvec) * inv_det;
+	if (v < 0.0f || u + v > 1.0f)
+		return false;
+	*t_out = T * inv_det;
+	return true;
+}
+
 // how far d_mt_core gets (work counters only): 0 = |det| < eps, 1 = u outside, 2 = v or u+v outside, 3 = t computed
 __device__ __forceinline__ int d_mt_stage(const float *tvec, const float *edge1, const float *edge2, const float *dir)
 {
@@ -213,6 +241,16 @@ __device__ __forceinline__ float d_intersect_tri(const float *tvec, const float 
 {
 	float t;
 	if (!d_mt_core(tvec, edge1, edge2, dir, &t))
+		return 0.0f;
+	return (t < oldt) ? t : 0.0f;
+}
+
+// intersectTri for rays of one origin, from the triangle's shared part (d_mt_shared)
+__device__ __forceinline__ float d_intersect_tri_shared(const float *tvec, const float *edge1, const float *edge2, const float *qvec,
+							float T, const float *dir, float oldt)
+{
+	float t;
+	if (!d_mt_core_shared(tvec, edge1, edge2, qvec, T, dir, &t))
 		return 0.0f;
 	return (t < oldt) ? t : 0.0f;
 }

@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      u32 *__restrict__ report, const u32 *__restrict__ status,
 						      const unsigned long long *__restrict__ work, u32 SLICES)
 {
-	__shared__ __attribute__((aligned(16))) float lds[64 * TRI_STRIDE];
+	__shared__ __attribute__((aligned(16))) float lds[64 * 16]; // per survivor: tvec, e1, e2, then the part all rays share: qvec, T
 	const int lane = threadIdx.x;
 	// every kernel that raises a status bit or counts work has finished: complete the pass's report
 	if (blockIdx.x == 0 && lane == 0) {
@@ -1564,18 +1564,23 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 			const u32 cnt = (u32)__popcll(mask);
 			__syncthreads();
 			if (keep) {
-				float4 *dst = reinterpret_cast<float4 *>(&lds[d_rank_in_mask(mask) * TRI_STRIDE]);
+				// (all rays start at the light: tvec x e1 and e2 . (tvec x e1) are the triangle's, formed here once)
+				float qv[3], T;
+				d_mt_shared(&t9[0], &t9[3], &t9[6], qv, &T);
+				float4 *dst = reinterpret_cast<float4 *>(&lds[d_rank_in_mask(mask) * 16u]);
 				dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
 				dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
-				dst[2] = make_float4(t9[8], 0.0f, 0.0f, 0.0f);
+				dst[2] = make_float4(t9[8], qv[0], qv[1], qv[2]);
+				dst[3] = make_float4(T, 0.0f, 0.0f, 0.0f);
 			}
 			__syncthreads();
 			if (!done) {
 				for (u32 k = 0; k < cnt; k++) {
-					const float4 *src = reinterpret_cast<const float4 *>(&lds[k * TRI_STRIDE]);
+					const float4 *src = reinterpret_cast<const float4 *>(&lds[k * 16u]);
 					const float4 a = src[0], c = src[1], e = src[2];
-					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x };
-					const float value = d_intersect_tri(tv, e1, e2, r.rd, 999999.9f);
+					const float T = lds[k * 16u + 12u];
+					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e.x }, qv[3] = { e.y, e.z, e.w };
+					const float value = d_intersect_tri_shared(tv, e1, e2, qv, T, r.rd, 999999.9f);
 					if (value != 0.0f) {
 						// light_kernel.cu:193-202 with isSmaller (:1-11)
 						float pt[3];

@@ -1550,10 +1550,20 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		}
 		// the candidates were found for the whole beam; this wave's 64 (still undecided) rays are a
 		// narrower packet, so each staged candidate is culled once more against their own box
-		const DirBox box = d_dir_box(r.rd, !done);
+		DirBox box = d_dir_box(r.rd, !done);
+		unsigned long long boxed = __ballot(!done); // the rays the box was formed for
 		bool hit = false;
 		for (u32 b = p0; b < p1; b += 64) {
 			const u32 ncand = (p1 - b) < 64u ? (p1 - b) : 64u;
+			// rays flagged by the batches before need no more tests: once an eighth of the box's rays are gone the box is
+			// formed again for the rest (six wave reductions against ~35 instructions for every candidate it then culls)
+			{
+				const unsigned long long open = __ballot(!done);
+				if (8u * (u32)__popcll(open) <= 7u * (u32)__popcll(boxed)) {
+					box = d_dir_box(r.rd, !done);
+					boxed = open;
+				}
+			}
 			bool keep = false;
 			float t9[9];
 			if ((u32)lane < ncand) {

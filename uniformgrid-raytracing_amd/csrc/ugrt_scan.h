@@ -57,9 +57,10 @@ __device__ __forceinline__ u32 d_wave_incl_scan(u32 v, u32 lane)
 	return v;
 }
 
+// one tile of a scan of `tiles` tiles (the workgroups of a launch may serve two scans: k_scan_pair)
 template <bool INCLUSIVE, typename LOAD, typename TAIL, typename STORE>
-__global__ __launch_bounds__(SC_THREADS) void k_scan_tiles(LOAD load, u32 *__restrict__ out, u32 n, unsigned long long *state,
-							    u32 *ctrl, u32 epoch, u32 vec, TAIL tail, STORE store)
+__device__ __forceinline__ void d_scan_tile(const LOAD &load, u32 *__restrict__ out, u32 n, unsigned long long *state, u32 *ctrl,
+					    u32 epoch, u32 vec, const TAIL &tail, const STORE &store, u32 tiles)
 {
 	__shared__ u32 s_tile, s_wave[SC_WAVES], s_prefix;
 	const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -148,12 +149,31 @@ __global__ __launch_bounds__(SC_THREADS) void k_scan_tiles(LOAD load, u32 *__res
 		if (TAIL::active)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		const u32 done = atomicAdd(&ctrl[1], 1u);
-		if (done == gridDim.x - 1u) {
+		if (done == tiles - 1u) {
 			ctrl[0] = 0u;
 			ctrl[1] = 0u;
 			tail();
 		}
 	}
+}
+
+template <bool INCLUSIVE, typename LOAD, typename TAIL, typename STORE>
+__global__ __launch_bounds__(SC_THREADS) void k_scan_tiles(LOAD load, u32 *__restrict__ out, u32 n, unsigned long long *state,
+							    u32 *ctrl, u32 epoch, u32 vec, TAIL tail, STORE store)
+{
+	d_scan_tile<INCLUSIVE>(load, out, n, state, ctrl, epoch, vec, tail, store, gridDim.x);
+}
+
+// two scans of n words each in ONE launch (their inputs must not depend on each other): the first `tiles` workgroups
+// serve scan A, the others scan B, each with its own ticket and state words
+template <bool INCLUSIVE, typename LOAD>
+__global__ __launch_bounds__(SC_THREADS) void k_scan_pair(LOAD load_a, u32 *__restrict__ out_a, LOAD load_b, u32 *__restrict__ out_b, u32 n,
+							   unsigned long long *state, u32 *ctrl, u32 epoch, u32 vec, u32 tiles)
+{
+	if (blockIdx.x < tiles)
+		d_scan_tile<INCLUSIVE>(load_a, out_a, n, state, ctrl, epoch, vec, ScanTailNone(), ScanStoreNone(), tiles);
+	else
+		d_scan_tile<INCLUSIVE>(load_b, out_b, n, state + tiles, ctrl + 2, epoch, vec, ScanTailNone(), ScanStoreNone(), tiles);
 }
 
 // enqueues the scan on ctx->stream; out must be 16-byte aligned for `vec_out`
@@ -183,6 +203,37 @@ static int ugrt_scan_launch(ugrt_ctx *ctx, const LOAD &load, u32 *out, size_t n,
 	unsigned long long *state = (unsigned long long *)((char *)ctx->scan_state.p + 64);
 	hipLaunchKernelGGL((k_scan_tiles<INCLUSIVE, LOAD, TAIL, STORE>), dim3(tiles), dim3(SC_THREADS), 0, st, load, out, (u32)n, state,
 			   ctrl, ctx->scan_epoch, vec, tail, store);
+	UGRT_HIP(hipGetLastError());
+	return UGRT_OK;
+}
+
+// two scans of n words in one launch (k_scan_pair)
+template <bool INCLUSIVE, typename LOAD>
+static int ugrt_scan_launch_pair(ugrt_ctx *ctx, const LOAD &load_a, u32 *out_a, const LOAD &load_b, u32 *out_b, size_t n)
+{
+	if (n == 0)
+		return UGRT_OK;
+	if (n > 0x7FFFFFF0ull)
+		return ugrt_fail(UGRT_EINVAL, "scan: %zu words exceed the 32-bit index", n);
+	hipStream_t st = ctx->stream;
+	const u32 vec = ((((uintptr_t)out_a) | ((uintptr_t)out_b)) & 15u) == 0 ? 1u : 0u;
+	const u32 tiles = (u32)((n + SC_TILE - 1) / SC_TILE);
+	const void *before = ctx->scan_state.p;
+	int rc = ugrt_buf_reserve(ctx, ctx->scan_state, (size_t)tiles * 16 + 64);
+	if (rc)
+		return rc;
+	if (ctx->scan_state.p != before) {
+		UGRT_HIP(hipMemsetAsync(ctx->scan_state.p, 0, ctx->scan_state.cap, st));
+		ctx->scan_epoch = 0;
+	}
+	if (++ctx->scan_epoch >= (1u << 30)) {
+		UGRT_HIP(hipMemsetAsync(ctx->scan_state.p, 0, ctx->scan_state.cap, st));
+		ctx->scan_epoch = 1;
+	}
+	u32 *ctrl = (u32 *)ctx->scan_state.p;
+	unsigned long long *state = (unsigned long long *)((char *)ctx->scan_state.p + 64);
+	hipLaunchKernelGGL((k_scan_pair<INCLUSIVE, LOAD>), dim3(2u * tiles), dim3(SC_THREADS), 0, st, load_a, out_a, load_b, out_b, (u32)n,
+			   state, ctrl, ctx->scan_epoch, vec, tiles);
 	UGRT_HIP(hipGetLastError());
 	return UGRT_OK;
 }

@@ -926,11 +926,11 @@ __global__ __launch_bounds__(WL_THREADS) void k_shadow_runs(const K *__restrict_
 
 // per light cell: number of beams (ITEMS = false), or number of cull items = triangle batches x beam chunks -- formed
 // where the scans of these counts load them (ugrt_scan.h)
-template <bool ITEMS>
 struct ShadowCountLoad {
 	const u32 *span, *rstart, *rend;
 	u32 beam;
 	unsigned long long *tests;
+	bool ITEMS;
 	__device__ __forceinline__ void operator()(u32 base, u32 C, u32 (&v)[SC_ITEMS]) const
 	{
 #pragma unroll
@@ -1757,11 +1757,10 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	u32 XSEG = ctx->opt[UGRT_OPT_SHADOW_XSEG] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_XSEG] : 256u;
 	XSEG = XSEG < 64u ? 64u : (XSEG + 63u) / 64u * 64u;
 	{
-		const ShadowCountLoad<false> beams = { d_span, rstart, rend, beam, wcnt };
-		const ShadowCountLoad<true> items = { d_span, rstart, rend, beam, wcnt };
-		if ((rc = ugrt_scan_launch<true>(ctx, beams, gincl, C, ScanTailNone())))
-			return rc;
-		if ((rc = ugrt_scan_launch<true>(ctx, items, iincl, C, ScanTailNone())))
+		// (the beams and the cull items per cell: two scans over the light cells in one launch)
+		const ShadowCountLoad beams = { d_span, rstart, rend, beam, wcnt, false };
+		const ShadowCountLoad items = { d_span, rstart, rend, beam, wcnt, true };
+		if ((rc = ugrt_scan_launch_pair<true>(ctx, beams, gincl, items, iincl, C)))
 			return rc;
 	}
 	if ((rc = ugrt_buf_reserve(ctx, ctx->citem, (size_t)CULL_TABLE * sizeof(CullItem))))

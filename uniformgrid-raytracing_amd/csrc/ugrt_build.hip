@@ -477,11 +477,10 @@ __device__ __forceinline__ bool d_cell_active(const WideBox &wb, u32 c)
 // a kernel of its own): span = run end - run start (+ the wide triangles of an active cell), written back for the
 // tracers, the occupied cells counted with one atomic per tile of 4096 cells.
 struct SpanLoad {
-	u32 *cstart;  // run starts; `inv`: as the sort's last pass leaves them (~start, 0 = no run), put right here
+	const u32 *cstart;
 	u32 *span_io; // holds the run ends on entry
 	u32 *used;
 	WideBox wb;
-	bool inv;
 	__device__ __forceinline__ void operator()(u32 base, u32 n, u32 (&v)[SC_ITEMS]) const
 	{
 		__shared__ u32 s_used[SC_WAVES];
@@ -492,12 +491,7 @@ struct SpanLoad {
 			const u32 c = base + (u32)i;
 			u32 sp = 0;
 			if (c < n) {
-				u32 st = cstart[c];
-				if (inv) {
-					st = st ? ~st : 0u;
-					cstart[c] = st;
-				}
-				sp = span_io[c] - st;
+				sp = span_io[c] - cstart[c];
 				if (W && d_cell_active(wb, c))
 					sp += W;
 				span_io[c] = sp;
@@ -750,10 +744,8 @@ static int build_async_sort(ugrt_ctx *ctx, AsyncBuild *b, int n)
 	for (int i = 0; i < n; i++) {
 		Grid &G = *b[i].G;
 		const int gi = (int)(&G - ctx->grid);
-		// (the sort's last pass also records the cells' run bounds: no k_bounds behind it)
 		jobs[i] = RsJob{ (const u32 *)G.key[0].p, (const u32 *)G.val[0].p, (u32 *)G.key[1].p, (u32 *)G.val[1].p, b[i].launchRn,
-				 bits_for(b[i].C), (const u32 *)(ctx->d_small + UGRT_DSMALL_RW + 2 * gi),
-				 own_sort ? (u32 *)G.span.p + b[i].C : (u32 *)nullptr, own_sort ? (u32 *)G.span.p : (u32 *)nullptr };
+				 bits_for(b[i].C), (const u32 *)(ctx->d_small + UGRT_DSMALL_RW + 2 * gi) };
 	}
 	if (own_sort) {
 		rc = ugrt_sort_pairs_batch(ctx, jobs, n);
@@ -798,13 +790,11 @@ static int build_async_end(ugrt_ctx *ctx, AsyncBuild &b)
 	const u32 nparts = b.nparts;
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_BOUNDS);
 	u32 *cstart = (u32 *)G.span.p + C, *used = cstart + C;
-	const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1;
-	if (!own_sort) // (the built-in sort's last pass has recorded the run bounds)
-		hipLaunchKernelGGL(k_bounds, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, 0u, cstart, (u32 *)G.span.p,
-				   (const u32 *)rw);
+	hipLaunchKernelGGL(k_bounds, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, 0u, cstart, (u32 *)G.span.p,
+			   (const u32 *)rw);
 	// spans + offsets in one kernel; a grid without wide triangles ends its report there (with them: k_merge_wide)
 	{
-		SpanLoad sl = { cstart, (u32 *)G.span.p, used, wb, own_sort };
+		SpanLoad sl = { (const u32 *)cstart, (u32 *)G.span.p, used, wb };
 		SpanTail tl = { no_wide ? report + 2 : (u32 *)nullptr, (const u32 *)used, (const u32 *)status, wide_counter(G, F) };
 		if ((rc = ugrt_scan_launch<false>(ctx, sl, (u32 *)G.offset.p, (size_t)C, tl)))
 			return rc;
@@ -950,7 +940,6 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		return rc;
 	u32 *k0 = (u32 *)G.key[0].p, *k1 = (u32 *)G.key[1].p, *v0 = (u32 *)G.val[0].p, *v1 = (u32 *)G.val[1].p;
 	u32 *wl = (u32 *)G.wide.p, *wsorted = wl + F;
-	bool sorted_bounds = false; // the sort's last pass has recorded the cells' run bounds (~start, end)
 	if (Rn) {
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 		const u32 nparts = (Rn + BUILD_THREADS - 1) / BUILD_THREADS;
@@ -963,13 +952,8 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-		if (own_sort) { // (its last pass also records the cells' run bounds)
-			const RsJob job = { k0, v0, k1, v1, Rn, bits_for(C), nullptr, (u32 *)G.span.p + C, (u32 *)G.span.p };
-			rc = ugrt_sort_pairs_batch(ctx, &job, 1);
-			sorted_bounds = true;
-		} else {
-			rc = ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, Rn, bits_for(C));
-		}
+		rc = own_sort ? ugrt_sort_pairs_u32(ctx, k0, k1, v0, v1, Rn, bits_for(C), nullptr)
+			      : ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, Rn, bits_for(C));
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 		if (rc)
 			return rc;
@@ -992,7 +976,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	if (!Rn)
 		UGRT_HIP(hipMemsetAsync(G.span.p, 0, (size_t)C * 8 + 4, st)); // (otherwise cleared by k_fill)
 	if (R) {
-		if (Rn && !sorted_bounds) {
+		if (Rn) {
 			hipLaunchKernelGGL(k_bounds, dim3((Rn + BUILD_THREADS - 1) / BUILD_THREADS), dim3(BUILD_THREADS), 0,
 					   st, (const u32 *)k1, Rn, cstart, (u32 *)G.span.p, (const u32 *)nullptr);
 			UGRT_HIP(hipGetLastError());
@@ -1000,7 +984,7 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 	}
 	{
 		// spans + offsets in one kernel (an empty build: the cleared words are the spans)
-		SpanLoad sl = { cstart, (u32 *)G.span.p, used, wb, sorted_bounds };
+		SpanLoad sl = { (const u32 *)cstart, (u32 *)G.span.p, used, wb };
 		SpanTail tl = { (u32 *)nullptr, (const u32 *)used, (const u32 *)nullptr, wide_counter(G, F) };
 		if ((rc = ugrt_scan_launch<false>(ctx, sl, (u32 *)G.offset.p, (size_t)C, tl)))
 			return rc;

@@ -232,7 +232,6 @@ struct RsJob {
 	size_t n;
 	int end_bit;
 	const u32 *n_dev;
-	u32 *run_start, *run_end; // (optional) zeroed words per key value: the last pass leaves ~(start) and end of every key's run there
 };
 int ugrt_sort_pairs_batch(ugrt_ctx *ctx, const RsJob *jobs, int njobs, bool prehist = false);
 int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,

@@ -49,7 +49,6 @@ struct RsSeg {
 	u64w *look, *look2;    // [tile][digit] tile counts, [chunk][digit] chunk sums
 	u32 n, dmask, nmask;   // nmask: digit mask of the pass that follows (0: this is the segment's last pass)
 	u32 blocks;            // workgroups of this launch that belong to the segment
-	u32 *run_start, *run_end; // last pass only (else null): per key, ~(first position) and last position + 1 of its run (below)
 };
 struct RsBatch {
 	RsSeg s[RS_MAXSEG];
@@ -198,7 +197,7 @@ template <int RS_ITEMS, bool ATOMIC, bool FULL>
 __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32 *__restrict__ vin, u32 *__restrict__ kout,
 					  u32 *__restrict__ vout, u32 n, u32 shift, u32 dmask, u32 gdigit_in, u32 *hist_next, u32 nmask,
 					  u64w *look, u64w *look2, u32 epoch, u32 tile, u32 *s_keys, u32 *s_vals, u32 (*s_cnt)[RS_BINS],
-					  u32 *s_base, u32 *s_part, u32 *s_next, u32 *__restrict__ run_start, u32 *__restrict__ run_end)
+					  u32 *s_base, u32 *s_part, u32 *s_next)
 {
 	constexpr u32 RS_TILE = RS_THREADS * RS_ITEMS;
 	const u32 t = threadIdx.x, lane = t & 63u;
@@ -270,38 +269,12 @@ __device__ __forceinline__ void d_rs_tile(const u32 *__restrict__ kin, const u32
 	}
 	__syncthreads();
 	const u32 ntile = FULL ? (u32)RS_TILE : n - base;
-	if (run_start == nullptr) {
 #pragma unroll 4
-		for (u32 j = t; j < ntile; j += RS_THREADS) {
-			const u32 key = s_keys[j];
-			const u32 pos = s_base[(key >> shift) & dmask] + j;
-			kout[pos] = key;
-			vout[pos] = s_vals[j];
-		}
-		return;
-	}
-	// The last pass of a grid build's sort also records where every key's run starts and ends (what a kernel of its own
-	// did from the sorted list: k_bounds).  Inside a tile's run of one digit the sorted tile IS a stretch of the output,
-	// so a key that differs from its neighbour there is a run's first / last pair for certain (a plain store); the
-	// first and the last pair of a (tile, digit) run may or may not be: those go through atomicMax on ~position / on
-	// position + 1 (tiles x 256 of them), which are right in either order with the plain stores of the same key.  The
-	// words start at zero (a key without a run keeps 0 / 0).
 	for (u32 j = t; j < ntile; j += RS_THREADS) {
 		const u32 key = s_keys[j];
-		const u32 d = (key >> shift) & dmask;
-		const u32 pos = s_base[d] + j;
+		const u32 pos = s_base[(key >> shift) & dmask] + j;
 		kout[pos] = key;
 		vout[pos] = s_vals[j];
-		const u32 prev = j ? s_keys[j - 1u] : 0u, next = j + 1u < ntile ? s_keys[j + 1u] : 0u;
-		const bool in_run_p = j && ((prev >> shift) & dmask) == d, in_run_n = j + 1u < ntile && ((next >> shift) & dmask) == d;
-		if (!in_run_p)
-			atomicMax(&run_start[key], ~pos);
-		else if (prev != key)
-			run_start[key] = ~pos;
-		if (!in_run_n)
-			atomicMax(&run_end[key], pos + 1u);
-		else if (next != key)
-			run_end[key] = pos + 1u;
 	}
 }
 
@@ -352,10 +325,10 @@ __global__ __launch_bounds__(RS_THREADS, RS_ITEMS == 16 ? 4 : 6) void k_rs_pass(
 	if (base < n) {
 		if (n - base >= RS_TILE) // (no bounds checks in a full tile: all but the last)
 			d_rs_tile<RS_ITEMS, ATOMIC, true>(g.kin, g.vin, g.kout, g.vout, n, shift, g.dmask, gdigit_in, g.hist_next, g.nmask, g.look,
-							  g.look2, epoch, tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next, g.run_start, g.run_end);
+							  g.look2, epoch, tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
 		else
 			d_rs_tile<RS_ITEMS, ATOMIC, false>(g.kin, g.vin, g.kout, g.vout, n, shift, g.dmask, gdigit_in, g.hist_next, g.nmask, g.look,
-							   g.look2, epoch, tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next, g.run_start, g.run_end);
+							   g.look2, epoch, tile, s_keys, s_vals, s_cnt, s_base, s_part, s_next);
 	}
 	// the last workgroup to finish leaves this pass's histogram rows, ticket and counter at zero for the next sort
 	// (every workgroup has read the rows by now: a workgroup counts itself in after its own reads)
@@ -540,8 +513,6 @@ int ugrt_sort_pairs_batch(ugrt_ctx *ctx, const RsJob *jobs, int njobs, bool preh
 			g.dmask = (1u << bits_of_pass(j, p)) - 1u;
 			g.nmask = p + 1 < passes[j] ? (1u << bits_of_pass(j, p + 1)) - 1u : 0u;
 			g.blocks = blocks[j];
-			g.run_start = p + 1 == passes[j] ? jobs[j].run_start : (u32 *)nullptr;
-			g.run_end = p + 1 == passes[j] ? jobs[j].run_end : (u32 *)nullptr;
 		}
 		for (u32 k = b->nseg; k < RS_MAXSEG; k++)
 			b->s[k] = b->s[0];
@@ -610,6 +581,6 @@ int ugrt_sort_pairs_batch(ugrt_ctx *ctx, const RsJob *jobs, int njobs, bool preh
 int ugrt_sort_pairs_u32(ugrt_ctx *ctx, const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n, int end_bit,
 			const u32 *n_dev, bool prehist)
 {
-	const RsJob job = { kin, vin, kout, vout, n, end_bit, n_dev, nullptr, nullptr };
+	const RsJob job = { kin, vin, kout, vout, n, end_bit, n_dev };
 	return ugrt_sort_pairs_batch(ctx, &job, 1, prehist);
 }

@@ -570,22 +570,25 @@ __device__ __forceinline__ u32 d_pow2_ge(u32 n)
 // lists without common elements: element i of one lands at i + (smaller elements of the other).
 // Narrow side: one thread per reference (a cell may hold thousands).
 #define MERGE_LDS 1024
-// (block = its index among the narrow side's workgroups; s_w: MERGE_LDS words of the workgroup)
-__device__ __forceinline__ void d_merge_narrow(u32 block, u32 *s_w, const u32 *__restrict__ nkeys, const u32 *__restrict__ nvals, u32 Rn,
-					       const u32 *__restrict__ cstart, const u32 *__restrict__ offset, const u32 *__restrict__ wl,
-					       const WideBox &wb, u32 *__restrict__ okeys, u32 *__restrict__ ovals)
+__global__ __launch_bounds__(BUILD_THREADS) void k_merge_narrow(const u32 *__restrict__ nkeys,
+								 const u32 *__restrict__ nvals, u32 Rn,
+								 const u32 *__restrict__ cstart,
+								 const u32 *__restrict__ offset,
+								 const u32 *__restrict__ wl, WideBox wb,
+								 u32 *__restrict__ okeys, u32 *__restrict__ ovals)
 {
+	__shared__ u32 s_w[MERGE_LDS];
 	const u32 W = d_wide_count(wb);
 	if (wb.rw)
 		Rn = wb.rw[0];
-	if (block * BUILD_THREADS >= Rn)
+	if (blockIdx.x * BUILD_THREADS >= Rn)
 		return;
 	const bool w_lds = W <= MERGE_LDS;
 	if (w_lds)
 		for (u32 k = threadIdx.x; k < W; k += BUILD_THREADS)
 			s_w[k] = wl[k];
 	__syncthreads();
-	const u32 j = block * BUILD_THREADS + threadIdx.x;
+	const u32 j = blockIdx.x * BUILD_THREADS + threadIdx.x;
 	if (j >= Rn)
 		return;
 	const u32 c = nkeys[j], id = nvals[j];
@@ -597,56 +600,8 @@ __device__ __forceinline__ void d_merge_narrow(u32 block, u32 *s_w, const u32 *_
 	ovals[pos] = id;
 	okeys[pos] = c;
 }
-__global__ __launch_bounds__(BUILD_THREADS) void k_merge_narrow(const u32 *__restrict__ nkeys,
-								 const u32 *__restrict__ nvals, u32 Rn,
-								 const u32 *__restrict__ cstart,
-								 const u32 *__restrict__ offset,
-								 const u32 *__restrict__ wl, WideBox wb,
-								 u32 *__restrict__ okeys, u32 *__restrict__ ovals)
-{
-	__shared__ u32 s_w[MERGE_LDS];
-	d_merge_narrow(blockIdx.x, s_w, nkeys, nvals, Rn, cstart, offset, wl, wb, okeys, ovals);
-}
 
-// Wide side: one WAVE per active cell, the cell's narrow run is searched in LDS when it fits.  (wave = its index among
-// the wide side's `waves` waves; s_n: MERGE_LDS words of this wave.  A wave's LDS accesses execute in order: it needs no
-// barrier with itself, only the compiler must not move them past each other.)
-__device__ __forceinline__ void d_merge_wide(u32 wave, u32 waves, u32 *s_n, const u32 *__restrict__ nvals, const u32 *__restrict__ cstart,
-					     const u32 *__restrict__ span, const u32 *__restrict__ offset, const u32 *__restrict__ wl, u32 C,
-					     const WideBox &wb, u32 *__restrict__ okeys, u32 *__restrict__ ovals, u32 *__restrict__ report_tail,
-					     const u32 *__restrict__ used, const u32 *__restrict__ status)
-{
-	const u32 lane = threadIdx.x & 63u;
-	// the last kernel of an asynchronous build completes its report (written straight into the pinned host words)
-	if (report_tail && wave == 0u && lane == 0u) {
-		report_tail[0] = *used;
-		report_tail[1] = *status;
-	}
-	const u32 W = d_wide_count(wb);
-	if (W == 0u)
-		return;
-	for (u32 c = wave; c < C; c += waves) {
-		if (!d_cell_active(wb, c))
-			continue;
-		const u32 ns = span[c] - W;
-		const u32 *nv = nvals + cstart[c];
-		const u32 out = offset[c];
-		const bool n_lds = ns <= MERGE_LDS;
-		const u32 np2 = d_pow2_ge(ns);
-		__builtin_amdgcn_wave_barrier(); // the previous cell's s_n is no longer read
-		if (n_lds)
-			for (u32 i = lane; i < ns; i += 64u)
-				s_n[i] = nv[i];
-		__builtin_amdgcn_wave_barrier();
-		for (u32 k = lane; k < W; k += 64u) {
-			const u32 id = wl[k];
-			const u32 lb = n_lds ? d_lower_bound((const u32 *)s_n, ns, np2, id) : d_lower_bound(nv, ns, np2, id);
-			const u32 pos = out + k + lb;
-			ovals[pos] = id;
-			okeys[pos] = c;
-		}
-	}
-}
+// Wide side: one wave per active cell, the cell's narrow run is searched in LDS when it fits.
 __global__ __launch_bounds__(64) void k_merge_wide(const u32 *__restrict__ nvals, const u32 *__restrict__ cstart,
 						    const u32 *__restrict__ span, const u32 *__restrict__ offset,
 						    const u32 *__restrict__ wl, u32 C, WideBox wb,
@@ -655,25 +610,35 @@ __global__ __launch_bounds__(64) void k_merge_wide(const u32 *__restrict__ nvals
 						    const u32 *__restrict__ status)
 {
 	__shared__ u32 s_n[MERGE_LDS];
-	d_merge_wide(blockIdx.x, gridDim.x, s_n, nvals, cstart, span, offset, wl, C, wb, okeys, ovals, report_tail, used, status);
-}
-
-// both sides in ONE launch (they only share their inputs): the first `nblocks` workgroups are the narrow side's, each of
-// the others is four waves of the wide side
-__global__ __launch_bounds__(BUILD_THREADS) void k_merge_both(const u32 *__restrict__ nkeys, const u32 *__restrict__ nvals,
-							       const u32 *__restrict__ cstart, const u32 *__restrict__ span,
-							       const u32 *__restrict__ offset, const u32 *__restrict__ wl, u32 C, WideBox wb,
-							       u32 *__restrict__ okeys, u32 *__restrict__ ovals, u32 nblocks,
-							       u32 *__restrict__ report_tail, const u32 *__restrict__ used,
-							       const u32 *__restrict__ status)
-{
-	__shared__ u32 s_lds[(BUILD_THREADS / 64) * MERGE_LDS];
-	if (blockIdx.x < nblocks) {
-		d_merge_narrow(blockIdx.x, s_lds, nkeys, nvals, 0u, cstart, offset, wl, wb, okeys, ovals);
-	} else {
-		const u32 w = threadIdx.x >> 6, per = BUILD_THREADS / 64;
-		d_merge_wide((blockIdx.x - nblocks) * per + w, (gridDim.x - nblocks) * per, s_lds + w * MERGE_LDS, nvals, cstart, span, offset, wl, C,
-			     wb, okeys, ovals, report_tail, used, status);
+	const u32 lane = threadIdx.x;
+	// the last kernel of an asynchronous build completes its report (one copy then takes it to the host)
+	if (report_tail && blockIdx.x == 0 && lane == 0) {
+		report_tail[0] = *used;
+		report_tail[1] = *status;
+	}
+	const u32 W = d_wide_count(wb);
+	if (W == 0u)
+		return;
+	for (u32 c = blockIdx.x; c < C; c += gridDim.x) {
+		if (!d_cell_active(wb, c))
+			continue;
+		const u32 ns = span[c] - W;
+		const u32 *nv = nvals + cstart[c];
+		const u32 out = offset[c];
+		const bool n_lds = ns <= MERGE_LDS;
+		const u32 np2 = d_pow2_ge(ns);
+		__syncthreads(); // the previous cell's s_n is no longer read
+		if (n_lds)
+			for (u32 i = lane; i < ns; i += 64u)
+				s_n[i] = nv[i];
+		__syncthreads();
+		for (u32 k = lane; k < W; k += 64u) {
+			const u32 id = wl[k];
+			const u32 lb = n_lds ? d_lower_bound(s_n, ns, np2, id) : d_lower_bound(nv, ns, np2, id);
+			const u32 pos = out + k + lb;
+			ovals[pos] = id;
+			okeys[pos] = c;
+		}
 	}
 }
 
@@ -840,11 +805,12 @@ static int build_async_end(ugrt_ctx *ctx, AsyncBuild &b)
 		G.vals = v1;
 	} else {
 		// the merged lists go to key[0]/val[0]
-		// (both sides of the merge in one launch: they only share their inputs)
-		const u32 wwaves = C < 256u * 32u ? C : 256u * 32u, per = BUILD_THREADS / 64;
-		hipLaunchKernelGGL(k_merge_both, dim3(nparts + (wwaves + per - 1) / per), dim3(BUILD_THREADS), 0, st, (const u32 *)k1,
-				   (const u32 *)v1, (const u32 *)cstart, (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb,
-				   k0, v0, nparts, report + 2, (const u32 *)used, (const u32 *)status);
+		hipLaunchKernelGGL(k_merge_narrow, dim3(nparts), dim3(BUILD_THREADS), 0, st, (const u32 *)k1, (const u32 *)v1, 0u,
+				   (const u32 *)cstart, (const u32 *)G.offset.p, (const u32 *)wsorted, wb, k0, v0);
+		u32 blocks = C < 256u * 32u ? C : 256u * 32u;
+		hipLaunchKernelGGL(k_merge_wide, dim3(blocks), dim3(64), 0, st, (const u32 *)v1, (const u32 *)cstart,
+				   (const u32 *)G.span.p, (const u32 *)G.offset.p, (const u32 *)wsorted, C, wb, k0, v0, report + 2,
+				   (const u32 *)used, (const u32 *)status);
 		G.keys = k0;
 		G.vals = v0;
 	}

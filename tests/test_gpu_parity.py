@@ -1522,6 +1522,15 @@ def test_strict_texture_flag(ugrt, O, torch, W, H):
     assert same == (W == 1024)
 
 
+def test_short_reciprocal_equals_the_division_for_every_float(ugrt):
+    """The exact triangle tests invert det by v_rcp_f32 and one Newton step instead of the compiler's division sequence
+    (ugrt_dev.h d_recip_det).  The claim is that this is the SAME float as 1.0f / det for every det the tests can reach
+    (|det| >= 1e-21; 2^124 and above, infinities and NaNs take the division): the library runs all 2^32 bit patterns
+    through the function on the device and counts the operands whose result differs by a bit."""
+    ctx = ugrt.Context(64, 64)
+    assert ctx.get_state("recip_mismatches") == 0
+
+
 @pytest.mark.parametrize("async_build", [0, 1])
 def test_sort_options_through_a_frame(ugrt, O, torch, async_build):
     """The radix sort's forms under a whole frame (three grid builds, ray sort, the shadow tracer's three sorts): ranks by

@@ -210,7 +210,14 @@ extern "C" int ugrt_ctx_get_state(ugrt_ctx *ctx, const char *key, long long *val
 		*value = (long long)ctx->rs_launches;
 	else if (strcmp(key, "sort_rank_atomic") == 0)
 		*value = ctx->rs_atomic_rank < 0 ? -1 : (ctx->rs_atomic_rank == 1 && ctx->opt[UGRT_OPT_SORT_RANK] != 0 ? 1 : 0);
-	else
+	else if (strcmp(key, "recip_mismatches") == 0) {
+		// exhaustive: every float through the tracers' short reciprocal against the division (ugrt_dev.h d_recip_det)
+		unsigned long long bad = 0;
+		const int rc = ugrt_recip_selftest(ctx, &bad);
+		if (rc != UGRT_OK)
+			return rc;
+		*value = (long long)bad;
+	} else
 		return ugrt_fail(UGRT_EINVAL, "ctx_get_state: unknown key '%s'", key);
 	return UGRT_OK;
 }

@@ -155,6 +155,23 @@ __device__ __forceinline__ void d_ray_dir(const CamBlock &cam, const float *__re
 	D_NORMALIZE(ray_direction);
 }
 
+// inv_det = 1.0f / det of the Moller-Trumbore tests, for a det that has passed |det| >= D_EPSILON.
+// The compiler's division is v_div_scale x2, v_rcp, five FMAs, v_div_fmas, v_div_fixup: the scaling serves operands
+// whose reciprocal is (nearly) denormal or overflows.  v_rcp_f32 and ONE Newton step give the correctly rounded
+// reciprocal - the same bits as the division - for every float of magnitude [2^-125, 2^124): checked over all 2^32
+// bit patterns on the device (tools/recip_check.hip; ugrt_ctx_get_state "recip_mismatches" runs the same check on this
+// function, tests/test_gpu_parity.py).  D_EPSILON is 2^-70; a det of 2^124 or more, an infinity or a NaN takes the
+// division itself.  Seven vector instructions less per (triangle, ray) test, not a bit of difference.
+__device__ __forceinline__ float d_recip_det(float det)
+{
+	float r = __builtin_amdgcn_rcpf(det);
+	const float e = __builtin_fmaf(-det, r, 1.0f);
+	r = __builtin_fmaf(e, r, r);
+	if (__builtin_expect(!(__builtin_fabsf(det) < 0x1p124f), 0))
+		r = 1.0f / det;
+	return r;
+}
+
 // Common front half of trace_kernel.cu:4-33 / light_kernel.cu:13-40.
 // tri = {tvec[3], edge1[3], edge2[3]}.  Returns false when the reference
 // returns 0 before computing t; otherwise *t_out = DOT(edge2,qvec)*inv_det.
@@ -166,7 +183,7 @@ __device__ __forceinline__ bool d_mt_core(const float *tvec, const float *edge1,
 	float det = D_DOT(edge1, pvec);
 	if (det > -D_EPSILON && det < D_EPSILON)
 		return false;
-	float inv_det = 1.0f / det;
+	float inv_det = d_recip_det(det);
 	float u = D_DOT(tvec, pvec) * inv_det;
 	if (u < 0.0f || u > 1.0f)
 		return false;
@@ -195,7 +212,7 @@ __device__ __forceinline__ bool d_mt_core_shared(const float *tvec, const float 
 	float det = D_DOT(edge1, pvec);
 	if (det > -D_EPSILON && det < D_EPSILON)
 		return false;
-	float inv_det = 1.0f / det;
+	float inv_det = d_recip_det(det);
 	float u = D_DOT(tvec, pvec) * inv_det;
 	if (u < 0.0f || u > 1.0f)
 		return false;
@@ -214,7 +231,7 @@ __device__ __forceinline__ int d_mt_stage(const float *tvec, const float *edge1,
 	float det = D_DOT(edge1, pvec);
 	if (det > -D_EPSILON && det < D_EPSILON)
 		return 0;
-	float inv_det = 1.0f / det;
+	float inv_det = d_recip_det(det);
 	float u = D_DOT(tvec, pvec) * inv_det;
 	if (u < 0.0f || u > 1.0f)
 		return 1;

@@ -1618,6 +1618,41 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 	}
 }
 
+// Every float bit pattern through d_recip_det against the division it stands for (ugrt_dev.h); *mismatches = operands whose
+// reciprocal differs by a bit.  ugrt_ctx_get_state "recip_mismatches".
+__global__ __launch_bounds__(256) void k_recip_selftest(unsigned long long *bad)
+{
+	unsigned long long mine = 0;
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+		const float x = __uint_as_float((u32)i);
+		if (x > -D_EPSILON && x < D_EPSILON) // the tests return before they divide
+			continue;
+		const float want = 1.0f / x, got = d_recip_det(x);
+		const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);
+		mine += same ? 0u : 1u;
+	}
+	if (mine)
+		atomicAdd(bad, mine);
+}
+
+int ugrt_recip_selftest(ugrt_ctx *ctx, unsigned long long *mismatches)
+{
+	UGRT_HIP(hipSetDevice(ctx->device));
+	unsigned long long *d = nullptr;
+	UGRT_HIP(hipMalloc((void **)&d, sizeof *d));
+	hipError_t e = hipMemsetAsync(d, 0, sizeof *d, ctx->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_recip_selftest, dim3(4096), dim3(256), 0, ctx->stream, d);
+		e = hipMemcpyAsync(mismatches, d, sizeof *d, hipMemcpyDeviceToHost, ctx->stream);
+	}
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	UGRT_HIP(e);
+	return UGRT_OK;
+}
+
 static int bits_of(u32 v)
 {
 	int b = 1;

@@ -148,7 +148,8 @@ class Context:
         check(lib.ugrt_ctx_set_option(self._h, key.encode(), int(value)))
 
     def get_state(self, key):
-        """Counters and findings of the context: "radix_launches", "sort_rank_atomic"."""
+        """Counters and findings of the context: "radix_launches", "sort_rank_atomic", "recip_mismatches" (runs the
+        exhaustive check of the tracers' reciprocal on the device)."""
         v = C.c_longlong(0)
         check(lib.ugrt_ctx_get_state(self._h, key.encode(), C.byref(v)))
         return int(v.value)

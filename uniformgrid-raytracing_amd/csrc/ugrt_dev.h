@@ -272,18 +272,6 @@ __device__ __forceinline__ float d_intersect_tri_shared(const float *tvec, const
 	return (t < oldt) ? t : 0.0f;
 }
 
-// intersectTriUV for rays of one origin (the eye's primary rays), from the triangle's shared part
-__device__ __forceinline__ float d_intersect_tri_uv_shared(const float *tvec, const float *edge1, const float *edge2, const float *qvec,
-							   float T, const float *dir, float oldt)
-{
-	float t;
-	if (!d_mt_core_shared(tvec, edge1, edge2, qvec, T, dir, &t))
-		return 0.0f;
-	if (t < 0)
-		t *= -1;
-	return (t < oldt && t > 0) ? t : 0.0f;
-}
-
 // trace_kernel.cu:159-173 / light_kernel.cu:131-146: stage one triangle as
 // {origin - v0, v1 - v0, v2 - v0}
 __device__ __forceinline__ void d_stage_triangle(const float *__restrict__ verts, const int *__restrict__ tris,

@@ -1030,9 +1030,10 @@ def test_batched_light_and_uniform_builds(ugrt, O, torch, name, W, H, lg, ud):
         np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"], err_msg=what)
         np.testing.assert_array_equal(r.hit_id.cpu().numpy(), want["hit_id"], err_msg=what)
         np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"], err_msg=what)
-    # a batch is its passes once (the longer list's) and one histogram kernel; apart, the lists' passes add up
+    # a batch is its passes once (the longer list's) and one histogram kernel; apart, the lists' passes add up and no
+    # histogram kernel runs (a build's fill kernel counts the first digit of its keys itself)
     lb, ub = (bits_for_cells(lg[0] * lg[1]) + 7) // 8, (bits_for_cells(ud[0] * ud[1] * ud[2]) + 7) // 8
-    assert per_frame[2] == max(lb, ub) + 1 and per_frame[3] == lb + ub + 2, (per_frame, lb, ub)
+    assert per_frame[2] == max(lb, ub) + 1 and per_frame[3] == lb + ub, (per_frame, lb, ub)
     # one build inside a batch, and an empty batch
     r.aux.grid_build_batch_begin()
     r.aux.grid_build_uniform(r.d_faces, r.d_verts, r.F, r.bbmin, r.bbmax)

@@ -376,14 +376,18 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill_parts(const u32 *__restr
 	parts[b] = (u32)lo;
 }
 
-// (grid-stride over the workgroup-sized parts: a bounded number of workgroups)
+// (grid-stride over the workgroup-sized parts: a bounded number of workgroups -- fewer when they also count the keys'
+// first digit for the sort that follows, ugrt_rs_hist.h: each then ends with up to 256 global adds)
 #define FILL_MAX_BLOCKS 8192u
+#define FILL_MAX_BLOCKS_COUNTING 4096u
 __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ scan, const Rng *__restrict__ rng,
 							 const u32 *__restrict__ parts, u32 R, int ny, int nz,
 							 u32 *__restrict__ keys, u32 *__restrict__ vals,
-							 u32 *__restrict__ zero, u32 nzero, const u32 *__restrict__ rw)
+							 u32 *__restrict__ zero, u32 nzero, const u32 *__restrict__ rw, RsFirst hs)
 {
 	__shared__ u32 s_scan[FILL_LDS];
+	__shared__ u32 s_rsh[RS_BINS * RS_PRIV];
+	d_rs_zero(s_rsh, hs); // (the barrier at the head of the loop stands between this and the first count)
 	// the per-cell words the boundary kernels start from (run ends, run starts, cells_used) are cleared here
 	// instead of by a fill of their own
 	for (u32 i = blockIdx.x * BUILD_THREADS + threadIdx.x; i < nzero; i += gridDim.x * BUILD_THREADS)
@@ -430,10 +434,15 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_fill(const u32 *__restrict__ 
 			u32 ij = local / sz;
 			u32 j = ij % sy;
 			u32 i = ij / sy;
-			keys[r] = ((x0 + i) * (u32)ny + (y0 + j)) * (u32)nz + (z0 + k);
+			const u32 key = ((x0 + i) * (u32)ny + (y0 + j)) * (u32)nz + (z0 + k);
+			keys[r] = key;
 			vals[r] = (u32)f;
+			if (hs.hist)
+				d_rs_count(s_rsh, key & 0xFFu, true);
 		}
 	}
+	__syncthreads();
+	d_rs_flush(s_rsh, hs);
 }
 
 // do_scan_dump + cudppCompact + create_histogram (misc_kernel.cu:4-60,
@@ -725,9 +734,16 @@ static int build_async_begin(ugrt_ctx *ctx, AsyncBuild &b)
 	ugrt_prof_begin(ctx, UGRT_ST_BUILD_FILL);
 	hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, F, 0u, 0u, (u32 *)G.parts.p, chk);
-	hipLaunchKernelGGL(k_fill, dim3(nparts < FILL_MAX_BLOCKS ? nparts : FILL_MAX_BLOCKS), dim3(BUILD_THREADS), 0, st,
+	// the fill counts the first digit of its keys for the build's own sort, unless that sort shares its launches with
+	// another build's (ugrt_grid_build_batch_begin: the lists of a batch are counted by one histogram kernel)
+	RsFirst hs = { nullptr };
+	if (ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1 && !ctx->batch_open && (rc = ugrt_sort_first_digit(ctx, &hs)))
+		return rc;
+	b.prehist = hs.hist != nullptr;
+	const u32 fill_blocks = hs.hist ? FILL_MAX_BLOCKS_COUNTING : FILL_MAX_BLOCKS;
+	hipLaunchKernelGGL(k_fill, dim3(nparts < fill_blocks ? nparts : fill_blocks), dim3(BUILD_THREADS), 0, st,
 			   (const u32 *)G.scan.p, (const Rng *)G.rng.p, (const u32 *)G.parts.p, 0u, ny, nz, k0, v0, (u32 *)G.span.p,
-			   2u * C + 1u, (const u32 *)rw);
+			   2u * C + 1u, (const u32 *)rw, hs);
 	ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 	UGRT_HIP(hipGetLastError());
 	b.launchRn = launchRn, b.capW = capW, b.capR = capR, b.active = active, b.no_wide = no_wide, b.nparts = nparts;
@@ -748,7 +764,7 @@ static int build_async_sort(ugrt_ctx *ctx, AsyncBuild *b, int n)
 				 bits_for(b[i].C), (const u32 *)(ctx->d_small + UGRT_DSMALL_RW + 2 * gi) };
 	}
 	if (own_sort) {
-		rc = ugrt_sort_pairs_batch(ctx, jobs, n);
+		rc = ugrt_sort_pairs_batch(ctx, jobs, n, n == 1 && b[0].prehist);
 	} else {
 		for (int i = 0; i < n && !rc; i++)
 			rc = ugrt_prim_sort_pairs(ctx, jobs[i].kin, jobs[i].kout, jobs[i].vin, jobs[i].vout, jobs[i].n, jobs[i].end_bit, jobs[i].n_dev);
@@ -946,13 +962,17 @@ static int build_common(ugrt_ctx *ctx, Grid &G, int F, u32 C, int ny, int nz, in
 		hipLaunchKernelGGL(k_fill_parts, dim3((nparts + BUILD_THREADS) / BUILD_THREADS), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, F, Rn, nparts, (u32 *)G.parts.p, BuildCheck{ nullptr, 0u, 0u, 0ull, 0ull, nullptr, nullptr, nullptr });
 		const bool own_sort = ctx->opt[UGRT_OPT_SORT_LIBRARY] != 1 && Rn <= (1u << 30);
-		hipLaunchKernelGGL(k_fill, dim3(nparts < FILL_MAX_BLOCKS ? nparts : FILL_MAX_BLOCKS), dim3(BUILD_THREADS), 0, st,
+		RsFirst hs = { nullptr }; // the fill counts the first digit of its keys for the sort
+		if (own_sort && (rc = ugrt_sort_first_digit(ctx, &hs)))
+			return rc;
+		const u32 fill_blocks = hs.hist ? FILL_MAX_BLOCKS_COUNTING : FILL_MAX_BLOCKS;
+		hipLaunchKernelGGL(k_fill, dim3(nparts < fill_blocks ? nparts : fill_blocks), dim3(BUILD_THREADS), 0, st,
 				   (const u32 *)G.scan.p, (const Rng *)G.rng.p, (const u32 *)G.parts.p, Rn, ny, nz, k0, v0,
-				   (u32 *)G.span.p, 2u * C + 1u, (const u32 *)nullptr);
+				   (u32 *)G.span.p, 2u * C + 1u, (const u32 *)nullptr, hs);
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_FILL);
 		UGRT_HIP(hipGetLastError());
 		ugrt_prof_begin(ctx, UGRT_ST_BUILD_SORT);
-		rc = own_sort ? ugrt_sort_pairs_u32(ctx, k0, k1, v0, v1, Rn, bits_for(C), nullptr)
+		rc = own_sort ? ugrt_sort_pairs_u32(ctx, k0, k1, v0, v1, Rn, bits_for(C), nullptr, true)
 			      : ugrt_prim_sort_pairs(ctx, k0, k1, v0, v1, Rn, bits_for(C));
 		ugrt_prof_end(ctx, UGRT_ST_BUILD_SORT);
 		if (rc)

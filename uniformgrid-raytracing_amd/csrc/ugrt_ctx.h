@@ -121,6 +121,7 @@ struct AsyncBuild {
 	u32 C, launchRn, capW, nparts;
 	unsigned long long capR, active;
 	bool no_wide;
+	bool prehist; // the fill has counted the first digit of the keys for the sort (ugrt_rs_hist.h)
 };
 
 struct ProfPair {

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define UGRT_VERSION 104
+#define UGRT_VERSION 105
 
 enum {
 	UGRT_OK = 0,
@@ -207,7 +207,8 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64" shape the
  * shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix sort instead of the built-in
  * one, "sort_items" 8 / 16 pairs per thread of a radix pass (default: by size), "sort_rank" 0 = the passes rank by
- * ballots instead of LDS atomics; "dda_blocks", "primary_waves",
+ * ballots instead of LDS atomics, "ray_sort" 1 = the deferred ugrt_sort_rays sorts at once also where nothing needs it
+ * (see there); "dda_blocks", "primary_waves",
  * "shadow_waves": number of persistent single-wave workgroups of the bounce, the primary tracer and the two
  * shadow kernels (the primary tracer and the exact shadow pass run one wave per work item by default, "primary_xcd_run" /
  * "shadow_xcd_run" neighbouring items per XCD in turn; "primary_waves" set / "shadow_xcd_run" 0 restore their persistent
@@ -293,7 +294,13 @@ int ugrt_map_rays_to_light(ugrt_ctx *ctx, const float *d_t_value, const float *d
 int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity,
 		   unsigned *num_chunks);
 /* num_chunks may be NULL: the call then does not wait for the device; the count is passed on to
- * ugrt_trace_shadow as UGRT_CHUNKS_ON_DEVICE and can be fetched later (this call waits for the stream): */
+ * ugrt_trace_shadow as UGRT_CHUNKS_ON_DEVICE and can be fetched later (ugrt_sort_rays_chunks waits for the stream).
+ * In a context with UGRT_FLAG_SHADOW_ALL_CHUNKS this deferred form also puts off the SORT: the chunk list only decides
+ * which rays the reference's launch traces, with the flag that is every ray, and ugrt_trace_shadow reads the
+ * (pixel, light cell) pairs of d_map in any order.  d_map and d_prefix_map are then left as they are until
+ * ugrt_sort_rays_chunks is called, which sorts them (they must still hold what ugrt_map_rays_to_light wrote) and
+ * returns the count: processData's outputs on demand, two radix passes and five launches less in a frame that never
+ * asks.  Option "ray_sort" 1 sorts at once as before. */
 int ugrt_sort_rays_chunks(ugrt_ctx *ctx, unsigned *num_chunks);
 #define UGRT_CHUNKS_ON_DEVICE 0xFFFFFFFFu
 /* check_for_shadows(int), per_frame_funcs.h:139 -> mod_light_rckernel; same

@@ -28,7 +28,7 @@ def test_python_prototypes_cover_the_header(ugrt):
 
 
 def test_version_and_error_string(ugrt):
-    assert ugrt.lib.ugrt_version() == 104
+    assert ugrt.lib.ugrt_version() == 105
     rc = ugrt.lib.ugrt_scene_load_model(None, b"x")
     assert rc == ugrt.UGRT_EINVAL
     assert b"null" in ugrt.lib.ugrt_last_error()

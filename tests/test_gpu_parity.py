@@ -1523,6 +1523,48 @@ def test_strict_texture_flag(ugrt, O, torch, W, H):
     assert same == (W == 1024)
 
 
+def test_ray_sort_on_demand(ugrt, O, torch):
+    """Deferred ugrt_sort_rays under FLAG_SHADOW_ALL_CHUNKS: the frame does not sort the ray map (the chunk list only says
+    which rays the reference's launch traces - all of them with that flag - and the shadow tracer orders (pixel, cell)
+    pairs itself); the sorted map, the chunk starts and the chunk count are produced when they are asked for.  Checked:
+    the shadow flags with and without the sort ("ray_sort" 1), the radix launches a frame saves, processData's outputs
+    on demand after the frame (and after a second frame that overwrote the map), and that a context without the flag
+    always sorts."""
+    s = scene(ugrt, "crash")
+    W, H, lg = 256, 144, (64, 64)
+    setup = setup_for(ugrt, s, "ref")
+    want = O.frame(s, setup, W, H, light_grid=lg, all_chunks=True)
+    ctx, r = make(ugrt, s, W, H, lg, flags=ugrt.FLAG_SHADOW_ALL_CHUNKS)
+    launches = {}
+    for mode in (1, 0, -1):
+        ctx.set_option("ray_sort", mode)
+        r.display(setup, frame_cnt=1, shadows=True)  # (buffers sized, estimates taken)
+        ctx.synchronize()
+        before = ctx.get_state("radix_launches")
+        r.display(setup, frame_cnt=1, shadows=True)
+        ctx.synchronize()
+        launches[mode] = ctx.get_state("radix_launches") - before
+        np.testing.assert_array_equal(r.is_shadowed.cpu().numpy(), want["is_shadowed"], err_msg="ray_sort %d" % mode)
+        np.testing.assert_array_equal(r.image.cpu().numpy(), want["image"], err_msg="ray_sort %d" % mode)
+        if mode != 1:  # nothing sorted the map so far: cells in pixel order
+            cells = u32(r._d_map)[W * H:].astype(np.int64)
+            assert (np.diff(cells) < 0).any()
+        # processData's outputs, on demand
+        assert r.num_chunks == want["nchunks"]
+        np.testing.assert_array_equal(u32(r.d_map), want["map"])
+        np.testing.assert_array_equal(u32(r.prefix)[:r.num_chunks], want["prefix"][:want["nchunks"]])
+    passes = (bits_for_cells(lg[0] * lg[1] + 1) + 7) // 8
+    assert launches[0] == launches[-1] == launches[1] - (passes + 1), launches
+    # without the flag the chunk list decides what is traced: the deferred form sorts at once
+    ctx2, r2 = make(ugrt, s, W, H, lg)
+    r2.display(setup, frame_cnt=1, shadows=True)
+    ctx2.synchronize()
+    cells = u32(r2._d_map)[W * H:].astype(np.int64)
+    assert (np.diff(cells) >= 0).all()
+    want2 = O.frame(s, setup, W, H, light_grid=lg, all_chunks=False)
+    np.testing.assert_array_equal(r2.is_shadowed.cpu().numpy(), want2["is_shadowed"])
+
+
 def test_short_reciprocal_equals_the_division_for_every_float(ugrt):
     """The exact triangle tests invert det by v_rcp_f32 and one Newton step instead of the compiler's division sequence
     (ugrt_dev.h d_recip_det).  The claim is that this is the SAME float as 1.0f / det for every det the tests can reach

@@ -49,6 +49,7 @@ enum {
 	UGRT_OPT_SHADOW_XCD_RUN,   // "shadow_xcd_run": exact shadow pass: one wave per item, this many neighbouring items per XCD in turn (default 128); 0 = the persistent waves of round 2
 	UGRT_OPT_PRIMARY_CENTRE,   // "primary_centre": primary tracer, one wave per item: 0 = the runs of items in list order (default 1: from the middle of the list outwards)
 	UGRT_OPT_SORT_RANK,        // "sort_rank": radix pass: 0 = ranks by ballots, 1 / default = by LDS atomics where the device's self-test allows it
+	UGRT_OPT_RAY_SORT,         // "ray_sort": 1 = the deferred ugrt_sort_rays sorts at once; 0 / default = on demand (see ugrt_sort_rays)
 	UGRT_OPT_COUNT
 };
 
@@ -178,6 +179,7 @@ struct ugrt_ctx {
 	unsigned prof_mask = 0; // bit s = stage s is timed
 	unsigned chunk_capacity = 0; // prefix_capacity of the last ugrt_sort_rays
 	const unsigned *chunk_prefix = nullptr, *chunk_map = nullptr; // and the arrays it sorted / wrote
+	bool ray_sort_pending = false; // the deferred ugrt_sort_rays of these arrays has not been carried out (yet)
 	int opt[UGRT_OPT_COUNT];     // ugrt_ctx_set_option; -1 = the built-in default
 	std::vector<ProfPair> prof[UGRT_ST_COUNT];
 	std::vector<ProfPair> prof_pool;

@@ -121,12 +121,9 @@ static int key_bits(u32 nkeys)
 	return b;
 }
 
-extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity,
-			      unsigned *num_chunks)
+// the sort, the runs per light cell and the chunk starts (enqueued; the chunk count goes to the pinned host word)
+static int sort_rays_now(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity)
 {
-	if (!ctx || !d_map || !d_prefix_map)
-		return ugrt_fail(UGRT_EINVAL, "sort_rays: null argument");
-	UGRT_HIP(hipSetDevice(ctx->device));
 	hipStream_t st = ctx->stream;
 	const u32 n = (u32)ctx->npix;
 	const u32 ncell = (u32)ctx->cfg.light_nbx * (u32)ctx->cfg.light_nby + 1u; // + sentinel
@@ -175,11 +172,30 @@ extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix
 	}
 	UGRT_HIP(hipGetLastError());
 	ugrt_prof_end(ctx, UGRT_ST_SORT_RAYS);
+	ctx->ray_sort_pending = false;
+	return UGRT_OK;
+}
+
+extern "C" int ugrt_sort_rays(ugrt_ctx *ctx, unsigned *d_map, unsigned *d_prefix_map, unsigned prefix_capacity,
+			      unsigned *num_chunks)
+{
+	if (!ctx || !d_map || !d_prefix_map)
+		return ugrt_fail(UGRT_EINVAL, "sort_rays: null argument");
+	UGRT_HIP(hipSetDevice(ctx->device));
 	ctx->chunk_capacity = prefix_capacity;
 	ctx->chunk_prefix = d_prefix_map;
 	ctx->chunk_map = d_map;
-	if (!num_chunks)
-		return UGRT_OK; // deferred: the count stays on the device (UGRT_CHUNKS_ON_DEVICE) until ugrt_sort_rays_chunks
+	// Deferred form under UGRT_FLAG_SHADOW_ALL_CHUNKS: the chunk list only says WHICH rays the reference's launch traces,
+	// and with that flag it is all of them -- the shadow tracer reads (pixel, light cell) pairs in any order and puts them
+	// in (cell, direction) order itself.  The sort is then carried out when its results are asked for
+	// (ugrt_sort_rays_chunks), not before: two radix passes and five more launches that a frame does not need.
+	if (!num_chunks && (ctx->cfg.flags & UGRT_FLAG_SHADOW_ALL_CHUNKS) && ctx->opt[UGRT_OPT_RAY_SORT] != 1) {
+		ctx->ray_sort_pending = true;
+		return UGRT_OK;
+	}
+	int rc = sort_rays_now(ctx, d_map, d_prefix_map, prefix_capacity);
+	if (rc || !num_chunks)
+		return rc; // deferred: the count stays on the device (UGRT_CHUNKS_ON_DEVICE) until ugrt_sort_rays_chunks
 	return ugrt_sort_rays_chunks(ctx, num_chunks);
 }
 
@@ -188,6 +204,11 @@ extern "C" int ugrt_sort_rays_chunks(ugrt_ctx *ctx, unsigned *num_chunks)
 	if (!ctx || !num_chunks)
 		return ugrt_fail(UGRT_EINVAL, "sort_rays_chunks: null argument");
 	UGRT_HIP(hipSetDevice(ctx->device));
+	if (ctx->ray_sort_pending) { // the sort that ugrt_sort_rays(..., NULL) put off: its arrays still hold the unsorted map
+		int rc = sort_rays_now(ctx, const_cast<unsigned *>(ctx->chunk_map), const_cast<unsigned *>(ctx->chunk_prefix), ctx->chunk_capacity);
+		if (rc)
+			return rc;
+	}
 	UGRT_HIP(hipStreamSynchronize(ctx->stream));
 	*num_chunks = ctx->h_pinned[UGRT_PIN_CHUNKS];
 	if (*num_chunks > ctx->chunk_capacity)

@@ -1681,14 +1681,18 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	const bool on_device = num_chunks == UGRT_CHUNKS_ON_DEVICE; // ugrt_sort_rays(..., NULL) left the count there
 	const u32 launch_cap = (ctx->cfg.flags & UGRT_FLAG_SHADOW_ALL_CHUNKS) ? 0xFFFFFFFFu : (u32)ctx->nbx * (u32)ctx->nby;
 	const u32 *nchunks_dev = nullptr;
+	u32 nchunks_arg = num_chunks;
 	if (on_device) {
-		if (!ctx->cbase.p)
+		if (!ctx->ray_sort_pending && !ctx->cbase.p)
 			return ugrt_fail(UGRT_EINVAL, "trace_shadow: UGRT_CHUNKS_ON_DEVICE without a ugrt_sort_rays before");
 		if (ctx->chunk_prefix != d_prefix_map || ctx->chunk_map != d_map)
 			return ugrt_fail(UGRT_EINVAL, "trace_shadow: UGRT_CHUNKS_ON_DEVICE refers to the last ugrt_sort_rays, which "
 						      "sorted other arrays");
-		nchunks_dev = (const u32 *)ctx->cbase.p + C; // inclusive scan of the chunks per light cell, last entry
-		traced = num_chunks;                          // the keys kernel applies the launch rule itself
+		traced = num_chunks; // the keys kernel applies the launch rule itself
+		if (ctx->ray_sort_pending)
+			nchunks_arg = 0u; // every chunk is traced and none was formed: d_map is the unsorted map, all n rays count
+		else
+			nchunks_dev = (const u32 *)ctx->cbase.p + C; // inclusive scan of the chunks per light cell, last entry
 	} else if (launch_cap == 0xFFFFFFFFu) {
 		traced = num_chunks;
 	} else {
@@ -1754,7 +1758,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	const u32 kblocks = (u32)((n + WL_THREADS - 1) / WL_THREADS) < 768u ? (u32)((n + WL_THREADS - 1) / WL_THREADS) : 768u;
 	if (key64) {
 		hipLaunchKernelGGL(k_shadow_keys<true>, dim3(kblocks), dim3(WL_THREADS), 0, st,
-				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
+				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, nchunks_arg, nchunks_arg ? traced : 0u, n, C, d_span,
 				   d_cam_position, 30u, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity,
 				   (u32 *)wcnt, 5u, (u32 *)ctx->pseg.p, PAIR_SEGS * PAIR_SEG_STRIDE, RsFirst{ nullptr });
 		UGRT_HIP(hipGetLastError());
@@ -1766,7 +1770,7 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 		if (own_sort && (rc = ugrt_sort_first_digit(ctx, &hs)))
 			return rc;
 		hipLaunchKernelGGL(k_shadow_keys<false>, dim3(kblocks), dim3(WL_THREADS), 0, st,
-				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, num_chunks, traced, n, C, d_span,
+				   ctx->cam, d_t_value, d_ray_dir, d_map, d_prefix_map, nchunks_arg, nchunks_arg ? traced : 0u, n, C, d_span,
 				   d_cam_position, mbits, k0, v0, rstart, 2u * ncellk, nchunks_dev, launch_cap, ctx->chunk_capacity,
 				   (u32 *)wcnt, 5u, (u32 *)ctx->pseg.p, PAIR_SEGS * PAIR_SEG_STRIDE, hs);
 		UGRT_HIP(hipGetLastError());

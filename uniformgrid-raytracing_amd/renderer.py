@@ -125,8 +125,8 @@ class Renderer:
         self.dir = ctx.empty(3 * N, t.float32)
         self.is_shadowed = ctx.empty(N, t.int32)
         self.intersect_id = ctx.empty(N, t.int32)
-        self.d_map = ctx.empty(2 * ctx.npix, t.int32)
-        self.prefix = ctx.empty(ctx.prefix_capacity(), t.int32)
+        self._d_map = ctx.empty(2 * ctx.npix, t.int32)
+        self._prefix = ctx.empty(ctx.prefix_capacity(), t.int32)
         self.image = t.zeros(3 * N, dtype=t.uint8, device=ctx.device)
         self.cam_pos = ctx.empty(3, t.float32)
         # pinned staging for d_cam_position: a pageable-memory copy would make the host wait for the whole
@@ -161,6 +161,18 @@ class Renderer:
         if self._num_chunks == 0xFFFFFFFF:
             self._num_chunks = self.ctx.sort_rays_chunks()
         return self._num_chunks
+
+    # The ray map sorted by light cell and the chunk starts (processData's outputs).  With FLAG_SHADOW_ALL_CHUNKS a frame
+    # does not need them (ugrt_sort_rays, deferred form): they are produced when they are looked at.
+    @property
+    def d_map(self):
+        self.num_chunks
+        return self._d_map
+
+    @property
+    def prefix(self):
+        self.num_chunks
+        return self._prefix
 
     # Model::init_orig_list, scene.h:336
     def init_orig_list(self, size, offset):
@@ -211,16 +223,16 @@ class Renderer:
         lcam = make_camera(setup.light_camera, setup.fovy, self.aspect)
         ctx.upload_camera(lcam.camcoords)
         if shadows:
-            ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
+            ctx.map_rays_to_light(self.t, self.dir, self._d_map, self.cam_pos, PI_F, PI_F)
             if self.shards is not None:
                 self._sharded(GRID_SPHERICAL,
                               lambda: ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F))
             else:
                 ctx.grid_build_spherical(self.d_faces, self.d_verts, self.F, PI_F, PI_F)
             lvalue, lspan, loffset, _ = ctx.grid_ptrs(GRID_SPHERICAL)
-            self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
+            self._num_chunks = ctx.sort_rays(self._d_map, self._prefix, deferred=True)
             ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
-                             self.d_map, self.prefix, self.cam_pos, self._num_chunks)
+                             self._d_map, self._prefix, self.cam_pos, self._num_chunks)
         if not shade:
             return
         if reflect:
@@ -312,15 +324,15 @@ class Renderer:
                 primary_recorded.set()
             ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
             if shadows:
-                ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
-                self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
+                ctx.map_rays_to_light(self.t, self.dir, self._d_map, self.cam_pos, PI_F, PI_F)
+                self._num_chunks = ctx.sort_rays(self._d_map, self._prefix, deferred=True)
                 light_grid_recorded.wait()
                 if status["light_grid_failed"]:
                     raise RuntimeError("the light grid build on the side stream failed")
                 main.wait_event(ev_light_grid)
                 lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
                 ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir,
-                                 self.is_shadowed, self.d_map, self.prefix, self.cam_pos, self._num_chunks)
+                                 self.is_shadowed, self._d_map, self._prefix, self.cam_pos, self._num_chunks)
         except BaseException as e:
             failed = e
         finally:
@@ -389,12 +401,12 @@ class Renderer:
                           self.hit_id)
         ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
         if shadows:
-            ctx.map_rays_to_light(self.t, self.dir, self.d_map, self.cam_pos, PI_F, PI_F)
-            self._num_chunks = ctx.sort_rays(self.d_map, self.prefix, deferred=True)
+            ctx.map_rays_to_light(self.t, self.dir, self._d_map, self.cam_pos, PI_F, PI_F)
+            self._num_chunks = ctx.sort_rays(self._d_map, self._prefix, deferred=True)
             main.wait_event(ev_light_grid)
             lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
             ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
-                             self.d_map, self.prefix, self.cam_pos, self._num_chunks)
+                             self._d_map, self._prefix, self.cam_pos, self._num_chunks)
         main.wait_stream(side)
         if reflect:
             ctx.shade_reflect(self.image, self.normal, self.t, self.dir, self.intersect_id, self.cam_pos,
@@ -547,12 +559,12 @@ class BandedRenderer:
                 ctx = r.ctx
                 ctx.upload_camera(lcam.camcoords)  # dd_camcoords is the light's from here on (main.cu:170)
                 if shadows:
-                    ctx.map_rays_to_light(self.t, self.dir, r.d_map, r.cam_pos, PI_F, PI_F)
-                    r._num_chunks = ctx.sort_rays(r.d_map, r.prefix, deferred=True)
+                    ctx.map_rays_to_light(self.t, self.dir, r._d_map, r.cam_pos, PI_F, PI_F)
+                    r._num_chunks = ctx.sort_rays(r._d_map, r._prefix, deferred=True)
                     st.wait_event(ev_grids)
                     lvalue, lspan, loffset, _ = aux.grid_ptrs(GRID_SPHERICAL)
                     ctx.trace_shadow(lvalue, self.d_verts, self.d_faces, lspan, loffset, self.t, self.dir, self.is_shadowed,
-                                     r.d_map, r.prefix, r.cam_pos, r._num_chunks)
+                                     r._d_map, r._prefix, r.cam_pos, r._num_chunks)
         for r, st in zip(self.rs, self.streams):
             with t.cuda.stream(st):
                 ctx = r.ctx

@@ -661,6 +661,23 @@ def main():
             rr.synchronize()
         torch.cuda.synchronize()
         repeats.append((time.perf_counter() - r0) / args.steps * 1e3)
+    # The frame leaves processData's sort to whoever asks for its outputs (ugrt_sort_rays, deferred form with
+    # SHADOW_ALL_CHUNKS).  Beside the figure: the same K steps with that sort carried out in every frame ("ray_sort" 1).
+    ray_sort_kept = []
+    for _ in range(min(args.repeats, 2)):
+        for rr in renderers:
+            rr.ctx.set_option("ray_sort", 1)
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        gather.finish()
+        for rr in renderers:
+            rr.synchronize()
+        torch.cuda.synchronize()
+        ray_sort_kept.append((time.perf_counter() - r0) / args.steps * 1e3)
+    for rr in renderers:
+        rr.ctx.set_option("ray_sort", -1)
     split_stats = None
     # latency: the same K steps with ONE frame in flight (every frame is finished before the next one is started)
     latency_ms = None
@@ -996,6 +1013,7 @@ def main():
         "verified_against_single_context_frame": verified,
         "verify_mismatches_per_renderer": verify_detail,
         "repeat_ms_per_step": [round(x, 4) for x in repeats],
+        "ms_per_step_with_the_ray_sort_in_every_frame": [round(x, 4) for x in ray_sort_kept],
         "repeat_ms_per_step_one_frame_in_flight": [round(x, 4) for x in latency_repeats],
         "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
         "gpu_ms_per_step_in_kernels": round(gpu_ms, 4),

@@ -34,6 +34,24 @@ struct DirBox {
 	float lo[3], hi[3];
 };
 
+// The decision every packet cull ends with, from the centre +- half width of det, A = u det, B = v det and C = A + B - det
+// over the packet (margins m*).  Either sign of det gives the same three tests once the numerators are taken WITH that
+// sign (for det < 0: A - Ar > mA is -A + Ar < -mA, ...), so the sign bit of Dm is xor-ed into them and no branch is left:
+// the two-sided form cost ~45 instructions per box under nested divergent branches, this one ~20.  Same decisions (a
+// negation is exact); a NaN anywhere compares false = not culled.
+__device__ __forceinline__ bool d_cull_decide(float Dm, float Dr, float Am, float Ar, float Bm, float Br, float Cm, float Cr,
+					      float mA, float mB, float mD, float mC)
+{
+	const u32 sg = __float_as_uint(Dm) & 0x80000000u;
+	const float sA = __uint_as_float(__float_as_uint(Am) ^ sg), sB = __uint_as_float(__float_as_uint(Bm) ^ sg),
+		    sC = __uint_as_float(__float_as_uint(Cm) ^ sg);
+	const float aD = fabsf(Dm);
+	const bool one_sign = aD - Dr > mD;   // det > 0 (or < 0) for every direction of the box
+	const bool sane = aD + Dr < 1e15f;    // (the margins were sized for operands below that)
+	const bool out = (sA + Ar < -mA) | (sB + Br < -mB) | (sC - Cr > mC); // u < 0, v < 0, u + v > 1
+	return one_sign & sane & out;
+}
+
 __device__ __forceinline__ float d_wave_min(float v)
 {
 #pragma unroll
@@ -160,6 +178,17 @@ struct CullTri {
 struct CBox {
 	float c[3], r[3];
 };
+// a box of directions as centre and half width (the half width a little wide: far more than the rounding of c and r)
+__device__ __forceinline__ CBox d_cbox(const DirBox &b)
+{
+	CBox o;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		o.c[k] = 0.5f * (b.lo[k] + b.hi[k]);
+		o.r[k] = 0.5f * (b.hi[k] - b.lo[k]) * 1.0001f + 1e-6f;
+	}
+	return o;
+}
 
 // (The cull is outside the numeric contract: it only has to be conservative, and its margins are 2^6
 // times the rounding error, so its dot products may contract to FMAs; the exact tests never do.)
@@ -207,20 +236,13 @@ __device__ __forceinline__ bool d_cull_cr(const CullTri &t, const CBox &bx)
 #pragma clang fp contract(fast)
 	const float Dm = t.nD[0] * bx.c[0] + t.nD[1] * bx.c[1] + t.nD[2] * bx.c[2];
 	const float Dr = fabsf(t.nD[0]) * bx.r[0] + fabsf(t.nD[1]) * bx.r[1] + fabsf(t.nD[2]) * bx.r[2];
-	if (!(Dm + Dr < 1e15f && Dm - Dr > -1e15f))
-		return false;
 	const float Am = t.nA[0] * bx.c[0] + t.nA[1] * bx.c[1] + t.nA[2] * bx.c[2];
 	const float Ar = fabsf(t.nA[0]) * bx.r[0] + fabsf(t.nA[1]) * bx.r[1] + fabsf(t.nA[2]) * bx.r[2];
 	const float Bm = t.nB[0] * bx.c[0] + t.nB[1] * bx.c[1] + t.nB[2] * bx.c[2];
 	const float Br = fabsf(t.nB[0]) * bx.r[0] + fabsf(t.nB[1]) * bx.r[1] + fabsf(t.nB[2]) * bx.r[2];
 	const float Cm = t.nC[0] * bx.c[0] + t.nC[1] * bx.c[1] + t.nC[2] * bx.c[2];
 	const float Cr = fabsf(t.nC[0]) * bx.r[0] + fabsf(t.nC[1]) * bx.r[1] + fabsf(t.nC[2]) * bx.r[2];
-	const float mC = t.mA + t.mB + t.mD;
-	if (Dm - Dr > t.mD) // det > 0 for every direction of the box
-		return (Am + Ar < -t.mA) || (Bm + Br < -t.mB) || (Cm - Cr > mC);
-	if (Dm + Dr < -t.mD) // det < 0
-		return (Am - Ar > t.mA) || (Bm - Br > t.mB) || (Cm + Cr < -mC);
-	return false;
+	return d_cull_decide(Dm, Dr, Am, Ar, Bm, Br, Cm, Cr, t.mA, t.mB, t.mD, t.mA + t.mB + t.mD);
 }
 
 // The same test against four boxes that share one half width (the quadrants of a tile: their radii differ by a few per
@@ -239,17 +261,10 @@ __device__ __forceinline__ u32 d_cull_cr4(const CullTri &t, const CBox *bx, cons
 	for (int q = 0; q < 4; q++) {
 		const float *c = bx[q].c;
 		const float Dm = t.nD[0] * c[0] + t.nD[1] * c[1] + t.nD[2] * c[2];
-		bool out = false;
-		if (Dm + Dr < 1e15f && Dm - Dr > -1e15f) {
-			const float Am = t.nA[0] * c[0] + t.nA[1] * c[1] + t.nA[2] * c[2];
-			const float Bm = t.nB[0] * c[0] + t.nB[1] * c[1] + t.nB[2] * c[2];
-			const float Cm = t.nC[0] * c[0] + t.nC[1] * c[1] + t.nC[2] * c[2];
-			if (Dm - Dr > t.mD) // det > 0 for every direction of the box
-				out = (Am + Ar < -t.mA) || (Bm + Br < -t.mB) || (Cm - Cr > mC);
-			else if (Dm + Dr < -t.mD) // det < 0
-				out = (Am - Ar > t.mA) || (Bm - Br > t.mB) || (Cm + Cr < -mC);
-		}
-		culled |= out ? (1u << q) : 0u;
+		const float Am = t.nA[0] * c[0] + t.nA[1] * c[1] + t.nA[2] * c[2];
+		const float Bm = t.nB[0] * c[0] + t.nB[1] * c[1] + t.nB[2] * c[2];
+		const float Cm = t.nC[0] * c[0] + t.nC[1] * c[1] + t.nC[2] * c[2];
+		culled |= d_cull_decide(Dm, Dr, Am, Ar, Bm, Br, Cm, Cr, t.mA, t.mB, t.mD, mC) ? (1u << q) : 0u;
 	}
 	return culled;
 }

@@ -1341,14 +1341,7 @@ __global__ __launch_bounds__(64) void k_shadow_cull(CamBlock cam, const u32 *__r
 				const float Br = fabsf(nB[0]) * bx.rx + fabsf(nB[1]) * bx.ry + fabsf(nB[2]) * bx.rz;
 				const float Cm = nC[0] * bx.cx + nC[1] * bx.cy + nC[2] * bx.cz;
 				const float Cr = fabsf(nC[0]) * bx.rx + fabsf(nC[1]) * bx.ry + fabsf(nC[2]) * bx.rz;
-				bool cull = false;
-				if (Dm + Dr < 1e15f && Dm - Dr > -1e15f) {
-					if (Dm - Dr > mD) // det > 0 for every ray of the beam
-						cull = (Am + Ar < -mA) || (Bm + Br < -mB) || (Cm - Cr > mC);
-					else if (Dm + Dr < -mD) // det < 0
-						cull = (Am - Ar > mA) || (Bm - Br > mB) || (Cm + Cr < -mC);
-				}
-				keep = !cull;
+				keep = !d_cull_decide(Dm, Dr, Am, Ar, Bm, Br, Cm, Cr, mA, mB, mD, mC);
 			}
 			const unsigned long long mask = __ballot(keep);
 			if (mask != 0ull) {

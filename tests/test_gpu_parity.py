@@ -1565,6 +1565,14 @@ def test_ray_sort_on_demand(ugrt, O, torch):
     np.testing.assert_array_equal(r2.is_shadowed.cpu().numpy(), want2["is_shadowed"])
 
 
+def test_lane_reductions_without_the_lds_crossbar(ugrt):
+    """The tracers' box reductions run on DPP controls and gfx950's v_permlane16_swap / v_permlane32_swap (ugrt_packet.h)
+    instead of __shfl_xor (a ds_bpermute_b32 per step).  A reduction that misses lanes would give a box too small - wrong
+    culls - or, silently, one too large; the library compares them with the __shfl_xor forms on the device."""
+    ctx = ugrt.Context(64, 64)
+    assert ctx.get_state("lane_reduce_mismatches") == 0
+
+
 def test_short_reciprocal_equals_the_division_for_every_float(ugrt):
     """The exact triangle tests invert det by v_rcp_f32 and one Newton step instead of the compiler's division sequence
     (ugrt_dev.h d_recip_det).  The claim is that this is the SAME float as 1.0f / det for every det the tests can reach

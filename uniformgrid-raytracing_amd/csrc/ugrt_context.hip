@@ -217,6 +217,13 @@ extern "C" int ugrt_ctx_get_state(ugrt_ctx *ctx, const char *key, long long *val
 		if (rc != UGRT_OK)
 			return rc;
 		*value = (long long)bad;
+	} else if (strcmp(key, "lane_reduce_mismatches") == 0) {
+		// the DPP / permlane-swap reductions of the tracers against the same by __shfl_xor (ugrt_packet.h)
+		unsigned long long bad = 0;
+		const int rc = ugrt_lane_reduce_selftest(ctx, &bad);
+		if (rc != UGRT_OK)
+			return rc;
+		*value = (long long)bad;
 	} else
 		return ugrt_fail(UGRT_EINVAL, "ctx_get_state: unknown key '%s'", key);
 	return UGRT_OK;

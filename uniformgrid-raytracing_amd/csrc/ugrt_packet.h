@@ -52,34 +52,6 @@ __device__ __forceinline__ bool d_cull_decide(float Dm, float Dr, float Am, floa
 	return one_sign & sane & out;
 }
 
-__device__ __forceinline__ float d_wave_min(float v)
-{
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-		v = fminf(v, __shfl_xor(v, m));
-	return v;
-}
-__device__ __forceinline__ float d_wave_max(float v)
-{
-#pragma unroll
-	for (int m = 32; m >= 1; m >>= 1)
-		v = fmaxf(v, __shfl_xor(v, m));
-	return v;
-}
-
-// box of the directions of the lanes with `valid`; other lanes do not contribute
-__device__ __forceinline__ DirBox d_dir_box(const float *d, bool valid)
-{
-	DirBox bx;
-	const float inf = __builtin_huge_valf();
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		bx.lo[k] = d_wave_min(valid ? d[k] : inf);
-		bx.hi[k] = d_wave_max(valid ? d[k] : -inf);
-	}
-	return bx;
-}
-
 __device__ __forceinline__ void d_interval_dot(const float *n, const DirBox &bx, float *fmin, float *fmax)
 {
 #pragma clang fp contract(fast)
@@ -99,6 +71,46 @@ __device__ __forceinline__ bool d_cull(const float *tv, const float *e1, const f
 {
 #ifdef UGRT_DEBUG_CULL_ALL
 	return (tv[0] + tv[1] + tv[2] + e1[0] + e1[1] + e1[2] + e2[0] + e2[1] + e2[2]) != 12345.678f;
+// box of the directions of the lanes with `valid`; other lanes do not contribute (uniform: scalar registers)
+__device__ __forceinline__ DirBox d_dir_box(const float *d, bool valid)
+{
+	DirBox bx;
+	const float inf = __builtin_huge_valf();
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		bx.lo[k] = d_wave_fmin(valid ? d[k] : inf);
+		bx.hi[k] = d_wave_fmax(valid ? d[k] : -inf);
+	}
+	return bx;
+}
+
+// Exchanges for reductions over the lanes of an 8x8-pixel tile's QUADRANT (lane bits 0, 1, 3, 4) and then across the
+// quadrants (bits 2, 5), all wave-uniform control flow, every lane active.  Bits 0, 1 and 3 are DPP controls (the
+// operation folds into the instruction); bit 4 and bit 5 use gfx950's v_permlane16_swap / v_permlane32_swap: with both
+// operands the same value, one result holds the even rows (lower half) everywhere and the other the odd rows (upper
+// half), so op(r0, r1) is the exchange with lane ^ 16 (^ 32).  Bit 2 after bits 0, 1: the quads are uniform by then,
+// and row_half_mirror pairs the two quads of every 8 lanes.  (__shfl_xor is a ds_bpermute_b32 + wait per step.)
+#define D_DPP_XOR1 0xB1        // quad_perm:[1,0,3,2]
+#define D_DPP_XOR2 0x4E        // quad_perm:[2,3,0,1]
+#define D_DPP_XOR8 0x128       // row_ror:8
+#define D_DPP_HALF_MIRROR 0x141
+template <typename OP>
+__device__ __forceinline__ int d_quadrant_reduce(int v) // over lane bits 0, 1, 3, 4
+{
+	v = OP::op(v, d_dpp_i<D_DPP_XOR1>(0, v));
+	v = OP::op(v, d_dpp_i<D_DPP_XOR2>(0, v));
+	v = OP::op(v, d_dpp_i<D_DPP_XOR8>(0, v));
+	const auto r = __builtin_amdgcn_permlane16_swap((u32)v, (u32)v, false, false);
+	return OP::op((int)r[0], (int)r[1]);
+}
+template <typename OP>
+__device__ __forceinline__ int d_across_quadrants(int v) // of quadrant-uniform values: over lane bits 2 and 5
+{
+	v = OP::op(v, d_dpp_i<D_DPP_HALF_MIRROR>(0, v));
+	const auto r = __builtin_amdgcn_permlane32_swap((u32)v, (u32)v, false, false);
+	return OP::op((int)r[0], (int)r[1]);
+}
+
 #endif
 #pragma clang fp contract(fast)
 	float nA[3], nB[3], nD[3], nC[3];
@@ -341,5 +353,45 @@ __device__ __forceinline__ int d_ordered(float f)
 __device__ __forceinline__ float d_unordered(int b) { return __int_as_float(b ^ ((b >> 31) & 0x7FFFFFFF)); }
 __device__ __forceinline__ float d_wave_fmin(float v) { return d_unordered(d_wave_imin(d_ordered(v))); }
 __device__ __forceinline__ float d_wave_fmax(float v) { return d_unordered(d_wave_imax(d_ordered(v))); }
+
+// box of the directions of the lanes with `valid`; other lanes do not contribute (uniform: scalar registers)
+__device__ __forceinline__ DirBox d_dir_box(const float *d, bool valid)
+{
+	DirBox bx;
+	const float inf = __builtin_huge_valf();
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		bx.lo[k] = d_wave_fmin(valid ? d[k] : inf);
+		bx.hi[k] = d_wave_fmax(valid ? d[k] : -inf);
+	}
+	return bx;
+}
+
+// Exchanges for reductions over the lanes of an 8x8-pixel tile's QUADRANT (lane bits 0, 1, 3, 4) and then across the
+// quadrants (bits 2, 5), all wave-uniform control flow, every lane active.  Bits 0, 1 and 3 are DPP controls (the
+// operation folds into the instruction); bit 4 and bit 5 use gfx950's v_permlane16_swap / v_permlane32_swap: with both
+// operands the same value, one result holds the even rows (lower half) everywhere and the other the odd rows (upper
+// half), so op(r0, r1) is the exchange with lane ^ 16 (^ 32).  Bit 2 after bits 0, 1: the quads are uniform by then,
+// and row_half_mirror pairs the two quads of every 8 lanes.  (__shfl_xor is a ds_bpermute_b32 + wait per step.)
+#define D_DPP_XOR1 0xB1        // quad_perm:[1,0,3,2]
+#define D_DPP_XOR2 0x4E        // quad_perm:[2,3,0,1]
+#define D_DPP_XOR8 0x128       // row_ror:8
+#define D_DPP_HALF_MIRROR 0x141
+template <typename OP>
+__device__ __forceinline__ int d_quadrant_reduce(int v) // over lane bits 0, 1, 3, 4
+{
+	v = OP::op(v, d_dpp_i<D_DPP_XOR1>(0, v));
+	v = OP::op(v, d_dpp_i<D_DPP_XOR2>(0, v));
+	v = OP::op(v, d_dpp_i<D_DPP_XOR8>(0, v));
+	const auto r = __builtin_amdgcn_permlane16_swap((u32)v, (u32)v, false, false);
+	return OP::op((int)r[0], (int)r[1]);
+}
+template <typename OP>
+__device__ __forceinline__ int d_across_quadrants(int v) // of quadrant-uniform values: over lane bits 2 and 5
+{
+	v = OP::op(v, d_dpp_i<D_DPP_HALF_MIRROR>(0, v));
+	const auto r = __builtin_amdgcn_permlane32_swap((u32)v, (u32)v, false, false);
+	return OP::op((int)r[0], (int)r[1]);
+}
 
 #endif

@@ -157,14 +157,8 @@ __device__ __forceinline__ void d_finish_pixel(const CamBlock &cam, const Primar
 // quadrant), NaN (bits ~0) while one of them has no hit: positive floats and that sentinel order as unsigned ints
 __device__ __forceinline__ void d_quadrant_far(const unsigned long long *s_best, int lane, float *qfar)
 {
-	u32 tb = (u32)(s_best[lane] >> 32);
-#pragma unroll
-	for (int m = 1; m <= 16; m <<= 1) {
-		if (m == 4)
-			continue;
-		const u32 o = (u32)__shfl_xor((int)tb, m);
-		tb = o > tb ? o : tb;
-	}
+	// (positive floats and the sentinel ~0 order as unsigned ints; the reduction is made on int images: bit 31 flipped)
+	const u32 tb = (u32)d_quadrant_reduce<DOpMax>((int)((u32)(s_best[lane] >> 32) ^ 0x80000000u)) ^ 0x80000000u;
 #pragma unroll
 	for (int q = 0; q < 4; q++)
 		qfar[q] = __uint_as_float((u32)__builtin_amdgcn_readlane((int)tb, ((q & 1) << 2) | ((q & 2) << 4)));
@@ -254,25 +248,14 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 		float qrmax[3]; // the largest of the four quadrants' half widths, per component (d_cull_cr4)
 #pragma unroll
 		for (int k = 0; k < 3; k++) {
-			float lo = dir[k], hi = dir[k];
-#pragma unroll
-			for (int m = 1; m <= 16; m <<= 1) {
-				if (m == 4)
-					continue;
-				lo = fminf(lo, __shfl_xor(lo, m));
-				hi = fmaxf(hi, __shfl_xor(hi, m));
-			}
+			// (through the order-preserving int images of the floats: integer min / max fold into the DPP instruction)
+			const int ilo = d_quadrant_reduce<DOpMin>(d_ordered(dir[k])), ihi = d_quadrant_reduce<DOpMax>(d_ordered(dir[k]));
+			float lo = d_unordered(ilo), hi = d_unordered(ihi);
 			const float qc = 0.5f * (lo + hi);
 			const float qr = 0.5f * (hi - lo) * 1.0001f + 1e-6f; // far more than the rounding of c and r
-			{
-				float m = fmaxf(qr, __shfl_xor(qr, 4));
-				m = fmaxf(m, __shfl_xor(m, 32));
-				qrmax[k] = d_readlane(m, 0);
-			}
-			lo = fminf(lo, __shfl_xor(lo, 4));
-			hi = fmaxf(hi, __shfl_xor(hi, 4));
-			lo = fminf(lo, __shfl_xor(lo, 32));
-			hi = fmaxf(hi, __shfl_xor(hi, 32));
+			qrmax[k] = d_readlane(d_unordered(d_across_quadrants<DOpMax>(d_ordered(qr))), 0);
+			lo = d_unordered(d_across_quadrants<DOpMin>(ilo));
+			hi = d_unordered(d_across_quadrants<DOpMax>(ihi));
 			tb.c[k] = d_readlane(0.5f * (lo + hi), 0);
 			tb.r[k] = d_readlane(0.5f * (hi - lo) * 1.0001f + 1e-6f, 0);
 #pragma unroll
@@ -1637,6 +1620,68 @@ int ugrt_recip_selftest(ugrt_ctx *ctx, unsigned long long *mismatches)
 	hipError_t e = hipMemsetAsync(d, 0, sizeof *d, ctx->stream);
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_recip_selftest, dim3(4096), dim3(256), 0, ctx->stream, d);
+		e = hipMemcpyAsync(mismatches, d, sizeof *d, hipMemcpyDeviceToHost, ctx->stream);
+	}
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	UGRT_HIP(e);
+	return UGRT_OK;
+}
+
+// The cross-lane reductions of ugrt_packet.h (DPP controls, v_permlane16_swap / v_permlane32_swap) against the same
+// reductions by __shfl_xor, on pseudo-random values; *mismatches = lanes that differ.  ugrt_ctx_get_state "lane_reduce_mismatches".
+__global__ __launch_bounds__(64) void k_lane_reduce_selftest(unsigned long long *bad)
+{
+	const int lane = threadIdx.x;
+	u32 mine = 0;
+	for (u32 round = 0; round < 64u; round++) {
+		u32 x = (blockIdx.x * 64u + (u32)lane) * 2654435761u + round * 40503u;
+		x ^= x >> 15;
+		x *= 2246822519u;
+		x ^= x >> 13;
+		const int v = (int)x;
+		// inside the quadrants: lane bits 0, 1, 3, 4
+		int lo = v, hi = v;
+		for (int m = 1; m <= 16; m <<= 1) {
+			if (m == 4)
+				continue;
+			const int ol = __shfl_xor(lo, m), oh = __shfl_xor(hi, m);
+			lo = ol < lo ? ol : lo;
+			hi = oh > hi ? oh : hi;
+		}
+		const int qlo = d_quadrant_reduce<DOpMin>(v), qhi = d_quadrant_reduce<DOpMax>(v);
+		mine += (qlo != lo) + (qhi != hi);
+		// across them: bits 2 and 5
+		int alo = lo, ahi = hi;
+		for (int m = 4; m <= 32; m <<= 3) {
+			const int ol = __shfl_xor(alo, m), oh = __shfl_xor(ahi, m);
+			alo = ol < alo ? ol : alo;
+			ahi = oh > ahi ? oh : ahi;
+		}
+		mine += (d_across_quadrants<DOpMin>(qlo) != alo) + (d_across_quadrants<DOpMax>(qhi) != ahi);
+		// the whole wave, floats (a quarter of the lanes do not contribute)
+		const float f = __int_as_float((v & 0x3FFFFFFF) | 0x20000000) * ((v & 4) ? -1.0f : 1.0f);
+		const bool in = (v & 3) != 0;
+		float wlo = in ? f : __builtin_huge_valf(), whi = in ? f : -__builtin_huge_valf();
+		for (int m = 32; m >= 1; m >>= 1) {
+			wlo = fminf(wlo, __shfl_xor(wlo, m));
+			whi = fmaxf(whi, __shfl_xor(whi, m));
+		}
+		mine += (d_wave_fmin(in ? f : __builtin_huge_valf()) != wlo) + (d_wave_fmax(in ? f : -__builtin_huge_valf()) != whi);
+	}
+	if (mine)
+		atomicAdd(bad, (unsigned long long)mine);
+}
+
+int ugrt_lane_reduce_selftest(ugrt_ctx *ctx, unsigned long long *mismatches)
+{
+	UGRT_HIP(hipSetDevice(ctx->device));
+	unsigned long long *d = nullptr;
+	UGRT_HIP(hipMalloc((void **)&d, sizeof *d));
+	hipError_t e = hipMemsetAsync(d, 0, sizeof *d, ctx->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_lane_reduce_selftest, dim3(1024), dim3(64), 0, ctx->stream, d);
 		e = hipMemcpyAsync(mismatches, d, sizeof *d, hipMemcpyDeviceToHost, ctx->stream);
 	}
 	if (e == hipSuccess)

@@ -25,7 +25,7 @@ struct WItem {
 	u32 cell;  // primary: screen cell; shadow: chunk index
 	u32 begin; // first ref
 	u32 count; // refs in this item (at most one segment)
-	u32 multi; // primary: cell is split across items
+	u32 multi; // primary: bit 0 = the cell is split across items; bits 1..15 its row, bits 16..31 its column of cells
 };
 
 // ---------------------------------------------------------------------------
@@ -61,7 +61,8 @@ struct WlPrimaryStore {
 			const u32 i = base + (u32)k;
 			if (i >= n)
 				break;
-			const u32 cell = (i / rows) * nby + gy_lo + (i % rows);
+			const u32 cx = i / rows, cy = gy_lo + (i % rows);
+			const u32 cell = cx * nby + cy;
 			const u32 sp = span[cell], off = offset[cell], cnt = v[k];
 			const u32 first = incl[k] - cnt;
 			for (u32 s = 0; s < cnt; s++) {
@@ -70,7 +71,7 @@ struct WlPrimaryStore {
 				w.begin = off + s * SEG;
 				const u32 left = sp - s * SEG;
 				w.count = sp ? (left < SEG ? left : SEG) : 0u;
-				w.multi = cnt > 1;
+				w.multi = (cnt > 1 ? 1u : 0u) | (cy << 1) | (cx << 16); // (the tracer is spared two integer divisions per item)
 				items[first + s] = w;
 			}
 		}
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 		float rcx = 0.f;
 		if (REC && w.count)
 			id_next = value_list[w.begin + min((u32)lane, last)];
-		const int bx = (int)(w.cell / (u32)cam.nby), by = (int)(w.cell % (u32)cam.nby);
+		const int bx = (int)(w.multi >> 16), by = (int)((w.multi >> 1) & 0x7FFFu);
 		const int col = bx * 8 + (lane & 7), row = by * 8 + (lane >> 3);
 		const int pixelID = row * cam.W + col;
 		float dir[3];
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 			njobs = 0;
 		}
 		const unsigned long long mine = s_best[lane];
-		if (!w.multi) {
+		if (!(w.multi & 1u)) {
 			const bool hit = mine != ~0ull;
 			d_finish_pixel<REC>(cam, out, pixelID, dir, hit ? __uint_as_float((u32)(mine >> 32)) : 99999999.9f,
 					    hit ? (u32)mine : 0xFFFFFFFFu, value_list, verts, tris, rec);

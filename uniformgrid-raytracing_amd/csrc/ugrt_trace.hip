@@ -192,26 +192,27 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 	const u32 nitems = *nitems_p;
 	const float ex = cam.cc[0], ey = cam.cc[1], ez = cam.cc[2];
 	unsigned long long ps[PS_END] = { 0 };
-	// SLICES 1: persistent waves, a contiguous slice of the list per XCD; otherwise one wave per item, runs of SLICES >> 1
-	// items per XCD in turn (workgroup b runs on XCD b % 8)
+	// SLICES 1: persistent waves, a contiguous slice of the list per XCD; otherwise one wave per item, runs of
+	// 2^((SLICES >> 1) - 1) items per XCD in turn (workgroup b runs on XCD b % 8; a power of two: every wave maps its
+	// index, and a division by a launch parameter is ~35 instructions)
 	u32 first = blockIdx.x;
 	if (SLICES == 1u) {
 		first = d_xcd_block();
 	} else if (SLICES > 1u) {
-		const u32 run = SLICES >> 1, j = blockIdx.x >> 3;
-		u32 g = j / run; // round of eight runs
+		const u32 rl = (SLICES >> 1) - 1u, j = blockIdx.x >> 3;
+		u32 g = j >> rl; // round of eight runs
 		if (SLICES & 1u) {
 			// Centre out: the rounds are taken from the middle of the list outwards (mid, mid + 1, mid - 1, ...).  The list is
 			// in screen order, column by column, and the cells that cost most (the long lists a camera looks at) sit around the
 			// middle of the view: in list order their items start half-way through the launch and ARE its tail (the longest
 			// last four times the mean: profiles/r03_primary_timeline.txt); started first they are over when the cheap ones run out.
-			const u32 G = (nitems + 8u * run - 1u) / (8u * run);
+			const u32 G = (nitems + (8u << rl) - 1u) >> (rl + 3u);
 			if (g >= G)
 				return;
 			const u32 mid = (G - 1u) >> 1;
 			g = (g & 1u) ? mid + ((g + 1u) >> 1) : mid - (g >> 1);
 		}
-		first = (g * 8u + (blockIdx.x & 7u)) * run + j % run;
+		first = (((g << 3) + (blockIdx.x & 7u)) << rl) + (j & ((1u << rl) - 1u));
 	}
 	for (u32 it = first; it < nitems; it += gridDim.x) {
 		const WItem w = items[it];
@@ -694,7 +695,11 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	// going to XCD r % 8; 0 = item i to XCD i % 8.  128: the 1 M-triangle frame is indifferent up to 256 (0.254-0.258
 	// ms, 0.278 at 1024), the 79 k-triangle hall, whose items cost the same, likes them long (0.126 at 0-32, 0.119 at
 	// 128, 0.115 at 2048, 0.113 in the slices))
-	const u32 p_run = ctx->opt[UGRT_OPT_PRIMARY_XCD_RUN] >= 0 ? (u32)ctx->opt[UGRT_OPT_PRIMARY_XCD_RUN] : 128u;
+	u32 p_run = ctx->opt[UGRT_OPT_PRIMARY_XCD_RUN] >= 0 ? (u32)ctx->opt[UGRT_OPT_PRIMARY_XCD_RUN] : 128u;
+	u32 p_run_log2 = 0;
+	while (p_run >> (p_run_log2 + 1u))
+		p_run_log2++;
+	p_run = p_run ? 1u << p_run_log2 : 0u; // (a power of two: rounded down)
 	size_t one_each = cap;
 	if (p_run)
 		one_each = (cap + 8u * p_run - 1) / (8u * p_run) * (8u * p_run); // (a whole number of rounds of runs: the mapping is a permutation)
@@ -711,7 +716,7 @@ extern "C" int ugrt_trace_primary(ugrt_ctx *ctx, const unsigned *d_value_list, c
 	hipLaunchKernelGGL((k_trace_primary<REC_, COUNT_>), dim3(pwaves), dim3(64), 0, st, ctx->cam, tex,              \
 			   (const WItem *)items, (const u32 *)(incl + (ncell - 1)), d_value_list, d_vertlist, d_trilist, \
 			   (const float4 *)(REC_ ? ctx->trirec.p : nullptr), out, (u64 *)ctx->best.p, ctx->p0, pc, p_order, p_chunk, \
-			   p_slices ? 1u : (p_run << 1) | (p_run && ctx->opt[UGRT_OPT_PRIMARY_CENTRE] != 0 ? 1u : 0u))
+			   p_slices ? 1u : (p_run ? ((p_run_log2 + 1u) << 1) | (ctx->opt[UGRT_OPT_PRIMARY_CENTRE] != 0 ? 1u : 0u) : 0u))
 	if (counting) {
 		UGRT_HIP(hipMemsetAsync(pc, 0, UGRT_PRIMARY_STATS * 8, st));
 		if (use_rec)
@@ -1477,14 +1482,14 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 	// flagged by k_pair_items.)
 	const u32 total = item_cap;
 	const float lx = cam.cc[0], ly = cam.cc[1], lz = cam.cc[2];
-	// SLICES 1: persistent waves, a contiguous slice of the list per XCD; otherwise one wave per item, runs of SLICES >> 1
-	// items per XCD in turn (as the primary tracer)
+	// SLICES 1: persistent waves, a contiguous slice of the list per XCD; otherwise one wave per item, runs of
+	// 2^((SLICES >> 1) - 1) items per XCD in turn (as the primary tracer)
 	u32 first = blockIdx.x;
 	if (SLICES == 1u) {
 		first = d_xcd_block();
 	} else if (SLICES > 1u) {
-		const u32 run = SLICES >> 1, j = blockIdx.x >> 3;
-		first = ((j / run) * 8u + (blockIdx.x & 7u)) * run + j % run;
+		const u32 rl = (SLICES >> 1) - 1u, j = blockIdx.x >> 3;
+		first = ((((j >> rl) << 3) + (blockIdx.x & 7u)) << rl) + (j & ((1u << rl) - 1u));
 	}
 	for (u32 it = first; it < total; it += gridDim.x) {
 		const u32 sgm = item_seg[it], gs = item_sub[it];
@@ -2008,10 +2013,13 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	// them, which the cull pass always runs on) with a contiguous slice of the list per XCD
 	const int x_opt = ctx->opt[UGRT_OPT_SHADOW_XCD_RUN];
 	const bool x_persistent = x_opt == 0;
-	const u32 x_run = x_opt > 0 ? (u32)x_opt : 128u;
+	u32 x_run = x_opt > 0 ? (u32)x_opt : 128u, x_run_log2 = 0;
+	while (x_run >> (x_run_log2 + 1u))
+		x_run_log2++;
+	x_run = 1u << x_run_log2; // (a power of two: rounded down)
 	const u32 xwaves = x_persistent ? (u32)launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])
 					: (u32)(((size_t)xcap + 8u * x_run - 1) / (8u * x_run) * (8u * x_run));
-	const u32 xslices = x_persistent ? 1u : x_run << 1;
+	const u32 xslices = x_persistent ? 1u : (x_run_log2 + 1u) << 1;
 	if (use_rec)
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(xwaves), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,

@@ -1492,44 +1492,53 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		first = ((((j >> rl) << 3) + (blockIdx.x & 7u)) << rl) + (j & ((1u << rl) - 1u));
 	}
 	for (u32 it = first; it < total; it += gridDim.x) {
+		// The head of an item is a chain of loads that depend on each other, and the pass is as long as its four hundred
+		// thousand chains: what does not depend on a load is requested with it.  {entry} -> {the sub-group's "all flagged"
+		// word} -> {beam, candidate run} -> {pixel, rebuilt ray, ids of the first candidates} -> {flag of the pixel, the
+		// candidates' records}: five round trips where the straightforward order made ten (and two instead of five for the
+		// three quarters of the items that end at the word).  Indices are clamped, not masked: loads under a divergent
+		// branch are waited for at the join.
 		const u32 sgm = item_seg[it], gs = item_sub[it];
-		if (sgm > XSEG_LAST)
-			continue;
-		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list
-		const GBox bx = boxes[g];
-		const u32 p0 = pstart[g] + sgm * XSEG;
-		const u32 p1 = (sgm != XSEG_LAST && (p0 + XSEG) < pend[g]) ? (p0 + XSEG) : pend[g];
+		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list (a padding entry reads beam 0's word)
 		// Three quarters of the items find every ray of their sub-group flagged by an earlier segment (the
 		// point of the segment-major order).  The sub-group says so in one word, and the flags are looked
-		// at before the rays are rebuilt: an item that has nothing to do ends after one or two loads.
+		// at before the rays are rebuilt.
 		u32 *my_done = sub_done + (size_t)g * nsubmax + sub;
-		if (__hip_atomic_load(my_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+		const u32 all_flagged = __hip_atomic_load(my_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if ((sgm > XSEG_LAST) | (all_flagged != 0u))
 			continue;
-		const bool have_ray = 64u * sub + (u32)lane < bx.ray_count;
-		ShadowRay r;
-		r.rd[0] = r.rd[1] = r.rd[2] = 0.0f;
-		r.distance_b = 0.0f;
-		r.pixel = 0;
-		bool done = true; // rayDoneMap == 2
-		int pixel = 0;
-		if (have_ray) {
-			pixel = (int)ray_pixels[bx.ray_start + 64u * sub + lane];
-			// a ray already flagged by another segment of its beam needs no more tests
-			done = is_shadowed[pixel] == 1;
-		}
+		const GBox bx = boxes[g];
+		const u32 ps = pstart[g], pe = pend[g];
+		const u32 p0 = ps + sgm * XSEG;
+		const u32 p1 = (sgm != XSEG_LAST && (p0 + XSEG) < pe) ? (p0 + XSEG) : pe;
+		const u32 rl0 = 64u * sub + (u32)lane;
+		const bool have_ray = rl0 < bx.ray_count;
+		const u32 ri = bx.ray_start + (have_ray ? rl0 : bx.ray_count - 1u); // (a listed sub-group has a ray)
+		const int pixel = (int)ray_pixels[ri];
+		const float4 q = sray[ri]; // = d_shadow_ray(pixel), stored by k_shadow_boxes
+		const u32 id_first = pair_tri[min(p0 + (u32)lane, p1 - 1u)]; // (a listed segment has a candidate)
+		u32 id_next = pair_tri[min(p0 + 64u + (u32)lane, p1 - 1u)];   // (beyond the run: its last candidate again)
+		// a ray already flagged by another segment of its beam needs no more tests
+		float qx = q.x, qy = q.y, qz = q.z, qw = q.w;
+		// (all four requests go out together; the compiler would move the ones the early exit below does not need behind it)
+		asm volatile("" : "+v"(id_next), "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
+		const int flag = is_shadowed[pixel];
+		float t9n[9];
+		d_load_triangle<REC>(rec, verts, tris, id_first, lx, ly, lz, t9n);
+		// (the records are requested beside the flag, not behind the test of it)
+		asm volatile("" : "+v"(t9n[0]), "+v"(t9n[3]), "+v"(t9n[4]), "+v"(t9n[8]));
+		bool done = !have_ray | (flag == 1); // rayDoneMap == 2
 		if (__ballot(!done) == 0ull) {
 			if (lane == 0)
 				__hip_atomic_store(my_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			continue;
 		}
-		if (have_ray) {
-			const float4 q = sray[bx.ray_start + 64u * sub + lane]; // = d_shadow_ray(pixel), stored by k_shadow_boxes
-			r.rd[0] = q.x;
-			r.rd[1] = q.y;
-			r.rd[2] = q.z;
-			r.distance_b = q.w;
-			r.pixel = pixel;
-		}
+		ShadowRay r;
+		r.rd[0] = qx;
+		r.rd[1] = qy;
+		r.rd[2] = qz;
+		r.distance_b = qw;
+		r.pixel = pixel;
 		// the candidates were found for the whole beam; this wave's 64 (still undecided) rays are a
 		// narrower packet, so each staged candidate is culled once more against their own box
 		DirBox box = d_dir_box(r.rd, !done);
@@ -1546,12 +1555,15 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 					boxed = open;
 				}
 			}
-			bool keep = false;
+			// (this batch's records were requested a batch ago, the ids of the next one with them: now that batch's records
+			// are requested, and the ids of the one after)
 			float t9[9];
-			if ((u32)lane < ncand) {
-				d_load_triangle<REC>(rec, verts, tris, pair_tri[b + lane], lx, ly, lz, t9);
-				keep = !d_cull(&t9[0], &t9[3], &t9[6], box);
-			}
+#pragma unroll
+			for (int k = 0; k < 9; k++)
+				t9[k] = t9n[k];
+			d_load_triangle<REC>(rec, verts, tris, id_next, lx, ly, lz, t9n);
+			id_next = pair_tri[min(b + 128u + (u32)lane, p1 - 1u)];
+			const bool keep = (u32)lane < ncand && !d_cull(&t9[0], &t9[3], &t9[6], box);
 			const unsigned long long mask = __ballot(keep);
 			const u32 cnt = (u32)__popcll(mask);
 			__syncthreads();

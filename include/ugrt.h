@@ -204,7 +204,7 @@ int ugrt_ctx_set_stream(ugrt_ctx *ctx, void *hip_stream);
  * "dda_split_segments" segments a group is cut into at most (4; 1 = none is cut: the long groups only start first);
  * "primary_seg" triangles per primary work item; "primary_order" 0 = a flush's jobs run in list order
  * (default: nearest triangles first), "primary_chunk" jobs between two looks at the rays' closest hits;
- * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64" shape the
+ * "shadow_beam", "shadow_xseg", "shadow_sizebits", "shadow_itemsort", "shadow_mbits", "shadow_key64", "shadow_sieve" shape the
  * shadow tracer's private regrouping; "sort_library" 1 = rocPRIM's radix sort instead of the built-in
  * one, "sort_items" 8 / 16 pairs per thread of a radix pass (default: by size), "sort_rank" 0 = the passes rank by
  * ballots instead of LDS atomics, "ray_sort" 1 = the deferred ugrt_sort_rays sorts at once also where nothing needs it

@@ -447,14 +447,15 @@ LAUNCH_SHAPES = [("primary_centre", 0), ("primary_waves", 64), ("primary_waves",
                  ("primary_xcd_run", 7), ("primary_xcd_run", 4096), ("shadow_xcd_run", 0), ("shadow_xcd_run", 1),
                  ("shadow_xcd_run", 4096), ("shadow_waves", 64), ("primary_order", 0), ("primary_chunk", 4),
                  ("primary_chunk", 64), ("primary_seg", 64), ("shadow_beam", 64), ("shadow_beam", 8192), ("shadow_xseg", 64),
-                 ("shadow_sizebits", 0), ("shadow_itemsort", 0), ("shadow_mbits", 9)]
+                 ("shadow_sizebits", 0), ("shadow_itemsort", 0), ("shadow_mbits", 9), ("shadow_sieve", 0), ("shadow_sieve", 2),
+                 ("shadow_sieve", 5), ("shadow_sieve", 64)]
 
 
 @pytest.mark.parametrize("name,W,H", [("crash", 384, 216), ("hall", 256, 256)])
 def test_launch_shape_options_do_not_change_a_result(ugrt, O, torch, name, W, H):
     """include/ugrt.h says no launch-shape option changes a result.  Every one that selects another code path of the
     primary tracer or the shadow pass (persistent waves with XCD slices, XCD runs of any length, the persistent exact
-    pass, list-order flushes, the padding-entry skip behind the item capacity) runs here, alone and all at once, waiting
+    pass, sieve waves of any width in the exact pass, list-order flushes, the padding-entry skip behind the item capacity) runs here, alone and all at once, waiting
     and asynchronous builds: ids, t, shadow flags and the image equal the oracle's."""
     s = scene(ugrt, name)
     lg, ud = (64, 64), (32, 32, 16)

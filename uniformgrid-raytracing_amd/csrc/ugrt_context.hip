@@ -199,7 +199,7 @@ static const struct {
 	{ "async_build", 0, 1 },        { "primary_waves", 64, 1 << 20 },
 	{ "shadow_waves", 64, 1 << 20 }, { "dda_sort", 0, 1 }, { "primary_order", 0, 1 }, { "primary_chunk", 4, 64 }, { "sort_items", 8, 16 }, { "dda_cull_work", 1, 1 << 30 },
 	{ "dda_split", 0, 4 }, { "dda_split_load", 50, 100000 }, { "dda_split_segments", 1, 4 }, { "primary_xcd_run", 0, 4096 }, { "shadow_xcd_run", 0, 4096 },
-	{ "primary_centre", 0, 1 }, { "sort_rank", 0, 1 }, { "ray_sort", 0, 1 },
+	{ "primary_centre", 0, 1 }, { "sort_rank", 0, 1 }, { "ray_sort", 0, 1 }, { "shadow_sieve", 0, 64 },
 };
 
 extern "C" int ugrt_ctx_get_state(ugrt_ctx *ctx, const char *key, long long *value)

@@ -50,6 +50,7 @@ enum {
 	UGRT_OPT_PRIMARY_CENTRE,   // "primary_centre": primary tracer, one wave per item: 0 = the runs of items in list order (default 1: from the middle of the list outwards)
 	UGRT_OPT_SORT_RANK,        // "sort_rank": radix pass: 0 = ranks by ballots, 1 / default = by LDS atomics where the device's self-test allows it
 	UGRT_OPT_RAY_SORT,         // "ray_sort": 1 = the deferred ugrt_sort_rays sorts at once; 0 / default = on demand (see ugrt_sort_rays)
+	UGRT_OPT_SHADOW_SIEVE,     // "shadow_sieve": items a sieve wave of the exact shadow pass looks at (default 16; 0 / 1 = a wave per item)
 	UGRT_OPT_COUNT
 };
 

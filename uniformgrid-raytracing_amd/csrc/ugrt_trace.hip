@@ -1465,7 +1465,7 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 						      const float *__restrict__ cmPt, u32 XSEG, u32 *__restrict__ sub_done,
 						      u32 nsubmax, const float4 *__restrict__ sray, u32 item_cap,
 						      u32 *__restrict__ report, const u32 *__restrict__ status,
-						      const unsigned long long *__restrict__ work, u32 SLICES)
+						      const unsigned long long *__restrict__ work, u32 SLICES, u32 W0, u32 SIEVE, u32 NSIEVE)
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * 16]; // per survivor: tvec, e1, e2, then the part all rays share: qvec, T
 	const int lane = threadIdx.x;
@@ -1491,22 +1491,41 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		const u32 rl = (SLICES >> 1) - 1u, j = blockIdx.x >> 3;
 		first = ((((j >> rl) << 3) + (blockIdx.x & 7u)) << rl) + (j & ((1u << rl) - 1u));
 	}
-	for (u32 it = first; it < total; it += gridDim.x) {
-		// The head of an item is a chain of loads that depend on each other, and the pass is as long as its four hundred
-		// thousand chains: what does not depend on a load is requested with it.  {entry} -> {the sub-group's "all flagged"
-		// word} -> {beam, candidate run} -> {pixel, rebuilt ray, ids of the first candidates} -> {flag of the pixel, the
-		// candidates' records}: five round trips where the straightforward order made ten (and two instead of five for the
-		// three quarters of the items that end at the word).  Indices are clamped, not masked: loads under a divergent
-		// branch are waited for at the join.
-		const u32 sgm = item_seg[it], gs = item_sub[it];
-		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list (a padding entry reads beam 0's word)
+	// Which items a wave takes.  The list is sorted by segment, the first segments of all sub-groups come first and are
+	// where the work is: of the 325 k items of the bench frame 42 k do anything, 33 k of them among the first 40 k; the
+	// other 283 k find their sub-group flagged - 0.9 us each, but the chip starts fewer than four waves per ns, so they
+	// were 77 of the pass's 178 us, and the long items behind them (up to 80 us: lit rays meet every candidate) started
+	// late and were its tail (per-wave time stamps, profiles/r04_shadow_exact_timeline.txt).  So only the first W0 items
+	// (>= the number of sub-groups: rays / 64 + beams) get a wave each; behind them a SIEVE wave looks at SIEVE items at
+	// once, lane = item, and works off the few that have anything to do.  Its items lie NSIEVE apart: the working ones
+	// cluster (neighbouring sub-groups of a beam with lit rays) and must not meet in one wave.
+	// (persistent form: every wave takes single items, in a stride)
+	const bool persistent = SLICES == 1u;
+	for (u32 base = first; base < (persistent ? total : W0 + NSIEVE); base += gridDim.x) {
+		const bool sieve = !persistent && base >= W0; // (base = W0 + v: the sieve wave's first item)
+		const u32 n_v = sieve ? SIEVE : 1u, stride_v = sieve ? NSIEVE : 0u;
+		u32 sgm_v = XSEG_LAST + 1u, gs_v = 0u;
+		const u32 my_it = base + (u32)lane * stride_v;
+		if ((u32)lane < n_v && my_it < total) {
+			sgm_v = item_seg[my_it];
+			gs_v = item_sub[my_it];
+		}
 		// Three quarters of the items find every ray of their sub-group flagged by an earlier segment (the
 		// point of the segment-major order).  The sub-group says so in one word, and the flags are looked
-		// at before the rays are rebuilt.
+		// at before the rays are rebuilt.  (a padding entry reads beam 0's word)
+		const u32 flagged_v = __hip_atomic_load(sub_done + (size_t)(gs_v >> 7) * nsubmax + (gs_v & 127u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		unsigned long long todo = __ballot(sgm_v <= XSEG_LAST && flagged_v == 0u);
+	while (todo != 0ull) {
+		const int tl = (int)__builtin_ctzll(todo);
+		todo &= todo - 1ull;
+		// The head of an item is a chain of loads that depend on each other, and the pass is as long as its
+		// chains: what does not depend on a load is requested with it.  {entry} -> {the sub-group's "all flagged"
+		// word} -> {beam, candidate run} -> {pixel, rebuilt ray, ids of the first candidates} -> {flag of the pixel, the
+		// candidates' records}: five round trips where the straightforward order made ten.  Indices are clamped, not
+		// masked: loads under a divergent branch are waited for at the join.
+		const u32 sgm = (u32)__builtin_amdgcn_readlane((int)sgm_v, tl), gs = (u32)__builtin_amdgcn_readlane((int)gs_v, tl);
+		const u32 g = gs >> 7, sub = gs & 127u; // the sub-groups of a beam share its candidate list (a padding entry reads beam 0's word)
 		u32 *my_done = sub_done + (size_t)g * nsubmax + sub;
-		const u32 all_flagged = __hip_atomic_load(my_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if ((sgm > XSEG_LAST) | (all_flagged != 0u))
-			continue;
 		const GBox bx = boxes[g];
 		const u32 ps = pstart[g], pe = pend[g];
 		const u32 p0 = ps + sgm * XSEG;
@@ -1609,6 +1628,9 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 			is_shadowed[r.pixel] = 1;
 		if (__ballot(!done) == 0ull && lane == 0)
 			__hip_atomic_store(my_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+		if (!persistent)
+			break;
 	}
 }
 
@@ -1848,8 +1870,9 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	beam = beam < 64u ? 64u : (beam > 8192u ? 8192u : (beam + 63u) / 64u * 64u);
 	// candidates per exact-pass work item: a 64-ray sub-group stops at the first batch after which all its
 	// rays are flagged, so long items cost little where everything is in shadow; short items bound the
-	// work of a sub-group that stays lit
-	u32 XSEG = ctx->opt[UGRT_OPT_SHADOW_XSEG] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_XSEG] : 256u;
+	// work of a sub-group that stays lit (128 since the later segments' items go through sieve waves: twice the items
+	// were twice the waves to start before - 256 then; profiles/r04_shadow_sieve_sweep.txt)
+	u32 XSEG = ctx->opt[UGRT_OPT_SHADOW_XSEG] > 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_XSEG] : 128u;
 	XSEG = XSEG < 64u ? 64u : (XSEG + 63u) / 64u * 64u;
 	{
 		// (the beams and the cull items per cell: two scans over the light cells in one launch)
@@ -2029,21 +2052,32 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	while (x_run >> (x_run_log2 + 1u))
 		x_run_log2++;
 	x_run = 1u << x_run_log2; // (a power of two: rounded down)
+	// (the first W0 items - at least the first segments of all sub-groups, of which there are at most rays / 64 + beams -
+	// get a wave each, the rest go through sieve waves of `x_sieve` items: see the kernel)
+	const u32 x_sieve = ctx->opt[UGRT_OPT_SHADOW_SIEVE] >= 0 ? (u32)ctx->opt[UGRT_OPT_SHADOW_SIEVE] : 8u;
+	u32 xw0 = xcap, xnsieve = 0u;
+	if (!x_persistent && x_sieve > 1u) {
+		const unsigned long long firsts = (unsigned long long)n / 64u + G + 1u; // (asynchronous form: G is the bound the beams were checked against)
+		xw0 = firsts < xcap ? (u32)firsts : xcap;
+		xnsieve = (xcap - xw0 + x_sieve - 1u) / x_sieve;
+	}
 	const u32 xwaves = x_persistent ? (u32)launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])
-					: (u32)(((size_t)xcap + 8u * x_run - 1) / (8u * x_run) * (8u * x_run));
+					: (u32)(((size_t)xw0 + xnsieve + 8u * x_run - 1) / (8u * x_run) * (8u * x_run));
 	const u32 xslices = x_persistent ? 1u : (x_run_log2 + 1u) << 1;
 	if (use_rec)
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(xwaves), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt, xslices);
+				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt, xslices, xw0,
+				   x_sieve > 64u ? 64u : x_sieve, xnsieve);
 	else
 		hipLaunchKernelGGL(k_trace_shadow<false>, dim3(xwaves), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
 				   (const u32 *)ctx->tval[1].p, d_vertlist, d_trilist, rec, d_t_value, d_ray_dir, d_is_shadowed,
 				   (const u32 *)v1, d_cam_position, XSEG, pend + maxg, beam / 64u,
-				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt, xslices);
+				   (const float4 *)ctx->sray.p, xcap, report, (const u32 *)status, (const unsigned long long *)wcnt, xslices, xw0,
+				   x_sieve > 64u ? 64u : x_sieve, xnsieve);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
 	// (the pass's report -- {pairs, beams} as found in the asynchronous form: what the next pass is sized by; the status

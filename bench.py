@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 DDA_WAVES_THROUGHPUT, DDA_WAVES_ONE_FRAME = 3072, 1024
 DDA_RPW_THROUGHPUT = 64
-DDA_SPLIT_THROUGHPUT = 0  # split walks of the bounce (ugrt.h "dda_split"): off beside other frames, on (the default) alone
+DDA_SPLIT_THROUGHPUT = 1  # split walks of the bounce (ugrt.h "dda_split"): on (the default) beside other frames too since round 4
 SHADOW_WAVES_THROUGHPUT = 8192  # (the cull pass; round 2: 4096.  The exact pass runs one wave per work item since round 3)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -491,8 +491,10 @@ def main():
                 # other frames that is what counts (1.214 -> 1.195 ms per frame)
                 rr.aux.set_option("dda_rays_per_wave", DDA_RPW_THROUGHPUT)
                 # split walks (the long ray groups of the last bounce cut into segments on different waves) shorten the
-                # bounce by 5-15 % and one frame in flight by 2-3 %, but add a launch and the segments' extra windows: beside
-                # three other frames the chip has no idle waves to give them (4 runs: 1.198 against 1.183 ms per frame)
+                # bounce by 5-15 % and one frame in flight by 2-3 %, but add a launch and the segments' extra windows.  Round 3
+                # kept them off beside other frames (4 runs: 1.198 against 1.183 ms per frame); with round 4's frame the cost is
+                # within the run-to-run spread (0.977-0.993 against 0.979-1.000 ms) and the bounce is 0.31 instead of 0.36 ms
+                # there (0.44 instead of 0.38 of the 8 TB/s line): on, the library's default
                 rr.aux.set_option("dda_split", DDA_SPLIT_THROUGHPUT)
             for kv in opts:
                 k, v = kv.split("=")

@@ -301,34 +301,19 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 					ps[PS_BATCHES]++;
 					ps[PS_TILE_SURVIVORS] += (u32)__popcll(__ballot(keep));
 				}
-				if (__ballot(keep) != 0ull) {
-					u32 km = 0;
-					float tlow = 0.0f;
-					if (keep) {
-						tlow = d_cull_tlow(ct, &t9[6], tb);
-						const u32 out4 = d_cull_cr4(ct, qb, qrmax);
-#pragma unroll
-						for (int q = 0; q < 4; q++)
-							km |= (((out4 >> q) & 1u) || tlow > qfar[q]) ? 0u : (1u << q);
-					}
+				// The survivors of the tile cull are staged as they are; their quadrant culls, depth bounds and jobs are
+				// made at the flush, lane = staged triangle: there the wave is full, here a batch has ~24 of them on 64 lanes
+				// (the ~300 instructions of that part ran 110 k times for the bench frame, they now run 45 k times).
+				const unsigned long long mask = __ballot(keep);
+				if (mask != 0ull) {
 					if (COUNT)
 						ps[PS_BATCHES_KEPT]++;
-					keep = km != 0u;
-					const unsigned long long mask = __ballot(keep);
 					const u32 slot = nsurv + d_rank_in_mask(mask);
 					if (keep) {
 						float4 *dst = reinterpret_cast<float4 *>(&lds[slot * TRI_STRIDE]);
 						dst[0] = make_float4(t9[0], t9[1], t9[2], t9[3]);
 						dst[1] = make_float4(t9[4], t9[5], t9[6], t9[7]);
-						dst[2] = make_float4(t9[8], __uint_as_float(w.begin + b + lane), tlow, 0.0f);
-					}
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						const unsigned long long mq = __ballot((km >> q) & 1u);
-						const u32 qoff = (u32)(((q & 1) << 2) | ((q & 2) << 4));
-						if ((km >> q) & 1u)
-							jobs[njobs + d_rank_in_mask(mq)] = (unsigned short)(slot | (qoff << 7));
-						njobs += (u32)__popcll(mq);
+						dst[2] = make_float4(t9[8], __uint_as_float(w.begin + b + lane), 0.0f, 0.0f);
 					}
 					nsurv += (u32)__popcll(mask);
 				}
@@ -339,6 +324,33 @@ __global__ __launch_bounds__(64, 4) void k_trace_primary(CamBlock cam, const flo
 			// 16 rays of its quadrant is dropped (the rays of the bench scene cross eleven surfaces each; lists are
 			// in id order, so most triangles come after a nearer one).  lane = (job, ray): the exact per-ray test
 			// of the reference, four of the remaining jobs a round.
+			__syncthreads();
+			// quadrant culls, depth bounds, jobs: lane = staged triangle
+			for (u32 s0 = 0; s0 < nsurv; s0 += 64u) {
+				const u32 slot = s0 + (u32)lane;
+				u32 km = 0;
+				if (slot < nsurv) {
+					const float4 *src = reinterpret_cast<const float4 *>(&lds[slot * TRI_STRIDE]);
+					const float4 a = src[0], c = src[1];
+					const float e2x = lds[slot * TRI_STRIDE + 8u];
+					const float tv[3] = { a.x, a.y, a.z }, e1[3] = { a.w, c.x, c.y }, e2[3] = { c.z, c.w, e2x };
+					const CullTri ct = d_cull_prep(tv, e1, e2);
+					const float tlow = d_cull_tlow(ct, e2, tb);
+					const u32 out4 = d_cull_cr4(ct, qb, qrmax);
+#pragma unroll
+					for (int q = 0; q < 4; q++)
+						km |= (((out4 >> q) & 1u) || tlow > qfar[q]) ? 0u : (1u << q);
+					lds[slot * TRI_STRIDE + 10u] = tlow;
+				}
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const unsigned long long mq = __ballot((km >> q) & 1u);
+					const u32 qoff = (u32)(((q & 1) << 2) | ((q & 2) << 4));
+					if ((km >> q) & 1u)
+						jobs[njobs + d_rank_in_mask(mq)] = (unsigned short)(slot | (qoff << 7));
+					njobs += (u32)__popcll(mq);
+				}
+			}
 			__syncthreads();
 			if (COUNT) {
 				ps[PS_FLUSHES]++;

@@ -1465,6 +1465,11 @@ __global__ __launch_bounds__(WL_THREADS) void k_pair_items(const u32 *__restrict
 }
 
 // EXACT pass: item -> (beam, segment of its candidate list, 64-ray sub-group); lane = ray, the reference's test
+#ifdef UGRT_SHADOW_TIMELINE
+// Instrumented builds only (make EXTRA=-DUGRT_SHADOW_TIMELINE; tools/shadow_timeline.py): every wave of the exact pass
+// leaves its start and end time (s_memrealtime, 100 MHz) and the number of items it worked on.
+__device__ unsigned long long *g_shadow_tl;
+#endif
 template <bool REC>
 __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__restrict__ xincl, u32 G,
 						      const u32 *__restrict__ item_seg, const u32 *__restrict__ item_sub,
@@ -1481,6 +1486,10 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 {
 	__shared__ __attribute__((aligned(16))) float lds[64 * 16]; // per survivor: tvec, e1, e2, then the part all rays share: qvec, T
 	const int lane = threadIdx.x;
+#ifdef UGRT_SHADOW_TIMELINE
+	const unsigned long long tl0 = __builtin_amdgcn_s_memrealtime();
+	u32 tl_n = 0;
+#endif
 	// every kernel that raises a status bit or counts work has finished: complete the pass's report
 	if (blockIdx.x == 0 && lane == 0) {
 		report[2] = *status;
@@ -1528,6 +1537,9 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		const u32 flagged_v = __hip_atomic_load(sub_done + (size_t)(gs_v >> 7) * nsubmax + (gs_v & 127u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		unsigned long long todo = __ballot(sgm_v <= XSEG_LAST && flagged_v == 0u);
 	while (todo != 0ull) {
+#ifdef UGRT_SHADOW_TIMELINE
+		tl_n++;
+#endif
 		const int tl = (int)__builtin_ctzll(todo);
 		todo &= todo - 1ull;
 		// The head of an item is a chain of loads that depend on each other, and the pass is as long as its
@@ -1644,6 +1656,12 @@ __global__ __launch_bounds__(64) void k_trace_shadow(CamBlock cam, const u32 *__
 		if (!persistent)
 			break;
 	}
+#ifdef UGRT_SHADOW_TIMELINE
+	if (g_shadow_tl && lane == 0) {
+		g_shadow_tl[2 * (size_t)blockIdx.x] = tl0;
+		g_shadow_tl[2 * (size_t)blockIdx.x + 1] = (__builtin_amdgcn_s_memrealtime() << 8) | (tl_n & 255u);
+	}
+#endif
 }
 
 // Every float bit pattern through d_recip_det against the division it stands for (ugrt_dev.h); *mismatches = operands whose
@@ -2076,6 +2094,14 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 	const u32 xwaves = x_persistent ? (u32)launch_blocks_for(xcap, ctx->opt[UGRT_OPT_SHADOW_WAVES])
 					: (u32)(((size_t)xw0 + xnsieve + 8u * x_run - 1) / (8u * x_run) * (8u * x_run));
 	const u32 xslices = x_persistent ? 1u : (x_run_log2 + 1u) << 1;
+#ifdef UGRT_SHADOW_TIMELINE
+	unsigned long long *tlbuf = nullptr;
+	if (getenv("UGRT_SHADOW_TIMELINE_FILE")) {
+		UGRT_HIP(hipMalloc((void **)&tlbuf, (size_t)xwaves * 16));
+		UGRT_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_shadow_tl), &tlbuf, sizeof tlbuf, 0, hipMemcpyHostToDevice, st));
+		fprintf(stderr, "[shadow timeline] waves %u single-item waves %u sieve waves %u of %u items, %u item slots\n", xwaves, xw0, xnsieve, x_sieve, xcap);
+	}
+#endif
 	if (use_rec)
 		hipLaunchKernelGGL(k_trace_shadow<true>, dim3(xwaves), dim3(64), 0, st, ctx->cam,
 				   (const u32 *)xincl, Gcap, (const u32 *)iseg1, (const u32 *)isub1, (const GBox *)boxes, (const u32 *)pstart, (const u32 *)pend,
@@ -2092,6 +2118,23 @@ extern "C" int ugrt_trace_shadow(ugrt_ctx *ctx, const unsigned *d_value_list, co
 				   x_sieve > 64u ? 64u : x_sieve, xnsieve);
 	ugrt_prof_end(ctx, UGRT_ST_TRACE_SHADOW);
 	UGRT_HIP(hipGetLastError());
+#ifdef UGRT_SHADOW_TIMELINE
+	if (tlbuf) {
+		UGRT_HIP(hipStreamSynchronize(st));
+		unsigned long long *h = (unsigned long long *)malloc((size_t)xwaves * 16), *none = nullptr;
+		UGRT_HIP(hipMemcpy(h, tlbuf, (size_t)xwaves * 16, hipMemcpyDeviceToHost));
+		UGRT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_shadow_tl), &none, sizeof none));
+		FILE *f = fopen(getenv("UGRT_SHADOW_TIMELINE_FILE"), "wb");
+		if (f) {
+			const unsigned long long hdr[4] = { xwaves, xw0, xnsieve, x_run_log2 };
+			fwrite(hdr, 8, 4, f);
+			fwrite(h, 16, xwaves, f);
+			fclose(f);
+		}
+		free(h);
+		(void)hipFree(tlbuf);
+	}
+#endif
 	// (the pass's report -- {pairs, beams} as found in the asynchronous form: what the next pass is sized by; the status
 	// word; the work counters of ugrt_stats_get -- is in the pinned host words when the stream has got this far: the
 	// compaction and the exact pass write it there themselves)

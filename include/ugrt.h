@@ -225,7 +225,10 @@ int ugrt_ctx_set_option(ugrt_ctx *ctx, const char *key, int value);
 /* counters and findings of this context (no reference counterpart; the bench line and the tests read them):
  * "radix_launches" histogram + pass kernels of the built-in radix sort enqueued so far, "sort_rank_atomic" 1 = the radix passes rank by LDS
  * atomics (the context's self-test found them served in lane order on this device), 0 = by ballots, -1 = no sort
- * has run yet.  Unknown key: UGRT_EINVAL. */
+ * has run yet; "recip_mismatches" runs every float bit pattern through the tracers' short reciprocal on the device and
+ * returns the number of operands whose result differs from 1.0f / x (0), "lane_reduce_mismatches" compares the tracers'
+ * DPP / permlane-swap reductions with the same reductions by __shfl_xor (0): both wait for the stream.
+ * Unknown key: UGRT_EINVAL. */
 int ugrt_ctx_get_state(ugrt_ctx *ctx, const char *key, long long *value);
 int ugrt_ctx_synchronize(ugrt_ctx *ctx);
 void ugrt_ctx_destroy(ugrt_ctx *ctx);

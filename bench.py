@@ -1000,6 +1000,9 @@ def main():
             "bounce_split_walks": {"frames_in_flight": bool(DDA_SPLIT_THROUGHPUT) if len(renderers) > 1 else True,
                                    "one_frame_in_flight": True, "last_one_frame_in_flight": split_stats},
             "host_waits_inside_a_frame": bool(args.waiting_builds),
+            # processData's sort of the ray map by light cell: made when its outputs are asked for (every chunk is traced and
+            # the shadow tracer orders the rays itself); ms_per_step_with_the_ray_sort_in_every_frame is the other way
+            "ray_sort": "on demand" if not any(kv.startswith("ray_sort=") for kv in opts) else "as set by --opt",
             "static_geometry": not args.no_static_geometry,  # UGRT_FLAG_STATIC_GEOMETRY: triangle records kept between builds
             "ms_per_step_one_frame_in_flight": round(latency_ms, 4) if latency_ms else None,
             "n_gt_1_default": "weak scaling: the image grows with N at 16:9 (N = 4 is configs[3]'s 3840x2160); "

@@ -27,7 +27,7 @@
 
 /* (int)x as the reference's target hardware did it: round toward zero,
  * NaN -> 0, saturating.  (x86 would give INT_MIN for NaN; CUDA and CDNA give 0.) */
-UGRT_HD int ugrt_f2i(float x)
+UGRT_HD int ugrt_f2i_portable(float x)
 {
 	if (!(x == x))
 		return 0;
@@ -39,7 +39,7 @@ UGRT_HD int ugrt_f2i(float x)
 }
 
 /* (unsigned)x: round toward zero, NaN -> 0, negatives -> 0, saturating. */
-UGRT_HD unsigned int ugrt_f2u(float x)
+UGRT_HD unsigned int ugrt_f2u_portable(float x)
 {
 	if (!(x == x))
 		return 0u;
@@ -48,6 +48,31 @@ UGRT_HD unsigned int ugrt_f2u(float x)
 	if (x >= 4294967296.0f)
 		return 4294967295u;
 	return (unsigned int)x;
+}
+
+/* On the device these ARE one instruction each: v_cvt_i32_f32 / v_cvt_u32_f32 round toward zero, give 0 for a NaN
+ * and saturate (the portable forms spell that out in ~15 instructions and three nested branches).  Named by inline
+ * assembly because a C cast is undefined for the inputs that matter; checked against the portable forms over every
+ * float on the device (ugrt_ctx_get_state "f2i_mismatches"). */
+UGRT_HD int ugrt_f2i(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	int r;
+	asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+	return r;
+#else
+	return ugrt_f2i_portable(x);
+#endif
+}
+UGRT_HD unsigned int ugrt_f2u(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	unsigned int r;
+	asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+	return r;
+#else
+	return ugrt_f2u_portable(x);
+#endif
 }
 
 /* floorf without libm: exact for every float. */
@@ -91,9 +116,19 @@ UGRT_HD void ugrt_tex_linear8(float x, int N, int *i_out, float *alpha_out)
 }
 
 /* (int)floor(x) */
+UGRT_HD int ugrt_floor2i_portable(float x)
+{
+	return ugrt_f2i_portable(ugrt_floorf(x));
+}
 UGRT_HD int ugrt_floor2i(float x)
 {
-	return ugrt_f2i(ugrt_floorf(x));
+#if defined(__HIP_DEVICE_COMPILE__)
+	/* v_floor_f32 is exact for every float (it differs from ugrt_floorf only in the sign of a zero, which the
+	 * conversion drops) */
+	return ugrt_f2i(__builtin_floorf(x));
+#else
+	return ugrt_floor2i_portable(x);
+#endif
 }
 
 /*

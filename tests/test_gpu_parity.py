@@ -1566,6 +1566,14 @@ def test_ray_sort_on_demand(ugrt, O, torch):
     np.testing.assert_array_equal(r2.is_shadowed.cpu().numpy(), want2["is_shadowed"])
 
 
+def test_float_to_int_instructions_equal_the_portable_forms(ugrt):
+    """ugrt_f2i / ugrt_f2u / ugrt_floor2i pin the reference's float -> integer conversions down (NaN -> 0, saturating); on
+    the device they are v_cvt_i32_f32 / v_cvt_u32_f32 / v_floor_f32 instead of the portable forms' branches.  Every float
+    bit pattern, all three functions, on the device."""
+    ctx = ugrt.Context(64, 64)
+    assert ctx.get_state("f2i_mismatches") == 0
+
+
 def test_lane_reductions_without_the_lds_crossbar(ugrt):
     """The tracers' box reductions run on DPP controls and gfx950's v_permlane16_swap / v_permlane32_swap (ugrt_packet.h)
     instead of __shfl_xor (a ds_bpermute_b32 per step).  A reduction that misses lanes would give a box too small - wrong

@@ -217,6 +217,13 @@ extern "C" int ugrt_ctx_get_state(ugrt_ctx *ctx, const char *key, long long *val
 		if (rc != UGRT_OK)
 			return rc;
 		*value = (long long)bad;
+	} else if (strcmp(key, "f2i_mismatches") == 0) {
+		// the one-instruction device forms of ugrt_f2i / ugrt_f2u / ugrt_floor2i against the portable ones, every float
+		unsigned long long bad = 0;
+		const int rc = ugrt_f2i_selftest(ctx, &bad);
+		if (rc != UGRT_OK)
+			return rc;
+		*value = (long long)bad;
 	} else if (strcmp(key, "lane_reduce_mismatches") == 0) {
 		// the DPP / permlane-swap reductions of the tracers against the same by __shfl_xor (ugrt_packet.h)
 		unsigned long long bad = 0;

@@ -239,6 +239,7 @@ struct RsJob {
 };
 int ugrt_sort_pairs_batch(ugrt_ctx *ctx, const RsJob *jobs, int njobs, bool prehist = false);
 int ugrt_lane_reduce_selftest(ugrt_ctx *ctx, unsigned long long *mismatches); // ugrt_trace.hip: DPP / permlane-swap reductions against __shfl_xor
+int ugrt_f2i_selftest(ugrt_ctx *ctx, unsigned long long *mismatches); // ugrt_trace.hip: device float -> int forms against the portable ones
 int ugrt_recip_selftest(ugrt_ctx *ctx, unsigned long long *mismatches); // ugrt_trace.hip: d_recip_det against 1.0f / x, all floats
 int ugrt_prim_sort_pairs64(ugrt_ctx *ctx, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n,
 			   int end_bit);

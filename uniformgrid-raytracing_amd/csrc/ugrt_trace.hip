@@ -1761,6 +1761,40 @@ int ugrt_lane_reduce_selftest(ugrt_ctx *ctx, unsigned long long *mismatches)
 	return UGRT_OK;
 }
 
+// Every float bit pattern through the device forms of ugrt_f2i / ugrt_f2u / ugrt_floor2i (one or two instructions) against
+// the portable forms of include/ugrt_fmath.h; *mismatches = operands that differ in any of the three.
+// ugrt_ctx_get_state "f2i_mismatches".
+__global__ __launch_bounds__(256) void k_f2i_selftest(unsigned long long *bad)
+{
+	unsigned long long mine = 0;
+	const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+	for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+		const float x = __uint_as_float((u32)i);
+		const bool same = ugrt_f2i(x) == ugrt_f2i_portable(x) && ugrt_f2u(x) == ugrt_f2u_portable(x) &&
+				  ugrt_floor2i(x) == ugrt_floor2i_portable(x);
+		mine += same ? 0u : 1u;
+	}
+	if (mine)
+		atomicAdd(bad, mine);
+}
+
+int ugrt_f2i_selftest(ugrt_ctx *ctx, unsigned long long *mismatches)
+{
+	UGRT_HIP(hipSetDevice(ctx->device));
+	unsigned long long *d = nullptr;
+	UGRT_HIP(hipMalloc((void **)&d, sizeof *d));
+	hipError_t e = hipMemsetAsync(d, 0, sizeof *d, ctx->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_f2i_selftest, dim3(4096), dim3(256), 0, ctx->stream, d);
+		e = hipMemcpyAsync(mismatches, d, sizeof *d, hipMemcpyDeviceToHost, ctx->stream);
+	}
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(d);
+	UGRT_HIP(e);
+	return UGRT_OK;
+}
+
 static int bits_of(u32 v)
 {
 	int b = 1;
